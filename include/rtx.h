@@ -1,0 +1,268 @@
+/*
+ * rtx.h — C ABI of the MI355X-native per-pixel trace loop.
+ *
+ * This is the drop-in boundary for ONE path of gyng/rust-raytracer: the body of
+ *     Renderer::render(&self, camera: Camera, shared_scene: Arc<Scene>) -> Surface
+ *                                                   (src/raytracer/renderer.rs:30-65)
+ * i.e. render_tile (renderer.rs:67-103) + the recursive Renderer::trace
+ * (renderer.rs:105-247) with everything below it (ray.rs, octree.rs, geometry/,
+ * material/, light/).  The reference has no FFI of its own; its
+ * Scene is a graph of Box<dyn Trait> objects that cannot cross a language
+ * boundary, so the Rust side flattens its concrete types into the plain arrays
+ * below (INTEGRATION.md shows the `extern "C"` stub) and this library does the
+ * rest on the GPU.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer it passes in,
+ *     the library copies what it needs during rtx_scene_create;
+ *   - every entry point returns an rtx_status, nothing aborts or throws across
+ *     the ABI (the reference panics / process::exit(1): main.rs:66-111);
+ *   - there is NO CPU fallback: without a HIP device every call that needs one
+ *     fails with RTX_ERR_NO_DEVICE / RTX_ERR_HIP;
+ *   - a scene handle may be rendered from one host thread at a time;
+ *     independent handles are independent;
+ *   - all arithmetic is IEEE f64 with the reference's operation order.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rtx_status;
+enum {
+    RTX_OK = 0,
+    RTX_ERR_INVALID_ARGUMENT = 1,
+    RTX_ERR_NO_DEVICE = 2,
+    RTX_ERR_HIP = 3,
+    RTX_ERR_OUT_OF_MEMORY = 4,
+    RTX_ERR_LIMIT = 5,          /* scene exceeds a documented limit (octree levels, node count) */
+    RTX_ERR_QUEUE_OVERFLOW = 6  /* ray pool exhausted (raise rtx_options.pool_rays) */
+};
+
+/* ---- materials: src/material/materials/ (all files) --------------------------------- */
+enum { RTX_MAT_COOK_TORRANCE = 0, RTX_MAT_PHONG = 1, RTX_MAT_FLAT = 2 };
+
+/* One row per DISTINCT material (the reference clones one Box<Material> per
+ * triangle, util/import.rs:104; the flattening dedupes them).
+ * CookTorranceMaterial (cooktorrancematerial.rs:8-23): all fields; shine = roughness.
+ * PhongMaterial        (phongmaterial.rs:7-21): shine = shininess; gauss_constant unused.
+ * FlatMaterial         (flatmaterial.rs:6-8): diffuse = color; everything else ignored. */
+typedef struct rtx_material {
+    int32_t kind;
+    int32_t texture;         /* diffuse_texture: index into rtx_scene_desc.textures, -1 = None */
+    double k_a, k_d, k_s, k_sg, k_tg;
+    double ambient[3];
+    double diffuse[3];
+    double specular[3];
+    double transmission[3];
+    double shine;
+    double gauss_constant;
+    double glossiness;
+    double ior;
+} rtx_material;
+
+/* ---- textures: src/material/textures/ (all files) ------------------------------------ */
+enum { RTX_TEX_CHECKER = 0, RTX_TEX_UV = 1, RTX_TEX_IMAGE = 2 };
+
+typedef struct rtx_texture {
+    int32_t kind;
+    int32_t image;           /* RTX_TEX_IMAGE: index into rtx_scene_desc.images */
+    double color1[3];        /* CheckerTexture.color1 (checkertexture.rs:7) r,g,b in [0,1] */
+    double color2[3];
+    double scale;
+} rtx_texture;
+
+/* Surface as ImageTexture holds it (imagetexture.rs:7-9): RGBA8, row-major, row 0 first. */
+typedef struct rtx_image {
+    int32_t width, height;
+    const uint8_t *rgba;
+} rtx_image;
+
+/* ---- lights: src/light/lights/ (all files) ------------------------------------------- */
+enum { RTX_LIGHT_POINT = 0, RTX_LIGHT_SPHERE = 1 };
+
+typedef struct rtx_light {
+    int32_t kind;
+    int32_t reserved;
+    double position[3];
+    double color[3];
+    double radius;           /* SphereLight only (spherelight.rs:6-10) */
+} rtx_light;
+
+/* ---- primitives: src/geometry/prims/ (all files) -------------------------------------- */
+enum { RTX_PRIM_SPHERE = 0, RTX_PRIM_PLANE = 1, RTX_PRIM_TRIANGLE = 2 };
+
+/*
+ * The flattened Scene (src/scene/scene.rs:7-12).
+ *
+ * Primitive order matters: the reference's octree keeps finite prims in
+ * insertion order (octree.rs:19-20,38) and that order defines the prim id this
+ * library reports: prim_id = rank among finite prims in insertion order; planes
+ * (infinite, plane.rs:19-23) follow as n_finite + j; a miss is -1.
+ * order_kind/order_index give the insertion order over all prims (n_prims =
+ * n_spheres + n_planes + n_triangles entries).  If both are NULL the order is:
+ * all spheres, all triangles, all planes.
+ */
+typedef struct rtx_scene_desc {
+    int32_t n_spheres;
+    const double *sphere_center;    /* [n_spheres][3]  Sphere.center  (sphere.rs:13) */
+    const double *sphere_radius;    /* [n_spheres]     Sphere.radius  (sphere.rs:14) */
+    const int32_t *sphere_material; /* [n_spheres]     row of materials */
+
+    int32_t n_planes;
+    const double *plane_abcd;       /* [n_planes][4]   Plane.a,b,c,d  (plane.rs:12-15) */
+    const int32_t *plane_material;
+
+    int32_t n_triangles;
+    const double *tri_vertices;     /* [n_triangles][3][3]  Triangle.vertices (triangle.rs:90) */
+    const double *tri_normals;      /* [n_triangles][3][3]  Triangle.normals  (triangle.rs:94)  */
+    const double *tri_uv;           /* [n_triangles][3][2]  Triangle.texinfo  (triangle.rs:97)  */
+    const int32_t *tri_material;
+
+    int32_t n_prims;
+    const int32_t *order_kind;      /* [n_prims] RTX_PRIM_*  (or NULL) */
+    const int32_t *order_index;     /* [n_prims] index into the per-kind arrays (or NULL) */
+
+    int32_t n_materials;
+    const rtx_material *materials;
+    int32_t n_textures;
+    const rtx_texture *textures;
+    int32_t n_images;
+    const rtx_image *images;
+    int32_t n_lights;
+    const rtx_light *lights;        /* Scene.lights order (renderer.rs:114 folds in this order) */
+
+    double background[3];           /* Scene.background */
+    int32_t skybox_image[6];        /* CubeMap.faces[0..5] = left,right,down,up,front,back
+                                       (cubemap.rs:12-19); skybox_image[0] < 0 = no skybox */
+} rtx_scene_desc;
+
+/* Camera::new arguments (src/scene/camera.rs:26-28). */
+typedef struct rtx_camera {
+    double position[3];
+    double look_at[3];
+    double up[3];
+    double fov_deg;
+    uint32_t image_width;
+    uint32_t image_height;
+} rtx_camera;
+
+enum { RTX_RNG_CENTER = 0, RTX_RNG_PHILOX = 1 };
+
+/* RenderOptions (renderer.rs:14-21) + what the reference leaves to thread_rng()
+ * and num_cpus (main.rs:138). Zero-initialise, then set the five knobs. */
+typedef struct rtx_options {
+    uint32_t reflect_depth;
+    uint32_t refract_depth;
+    uint32_t shadow_samples;
+    uint32_t gloss_samples;
+    uint32_t pixel_samples;   /* SIDE of the sample grid: samples per pixel = pixel_samples^2 */
+    uint32_t rng_mode;        /* RTX_RNG_CENTER: every uniform draw is 0.5 (deterministic parity
+                                 mode); RTX_RNG_PHILOX: counter-based Philox4x32-10 keyed on
+                                 (seed, frame, pixel, subsample, path node, light, try) */
+    uint64_t seed;
+    uint32_t frame;           /* animation frame number, part of the RNG key */
+    /* Tile-row sharding for multi-GPU stills: image rows are cut into blocks
+     * of 8 (the reference's tile height, renderer.rs:42); this call renders the blocks b with
+     * b % shard_count == shard_index and leaves all other rows of the output untouched.
+     * shard_count == 0 means 1. */
+    uint32_t shard_index;
+    uint32_t shard_count;
+    uint32_t batch_rays;      /* rays traced per wavefront step (0 = default 4 Mi) */
+    uint32_t pool_rays;       /* capacity of the ray pool in rays (0 = default: 8 x batch) */
+    uint32_t flags;           /* RTX_FLAG_* */
+} rtx_options;
+
+enum {
+    RTX_FLAG_REFERENCE_ORDER = 1 /* closest-hit ties resolve exactly as the reference's unordered
+                                    DFS would (first visited wins, ray.rs:52-60): disables
+                                    near-to-far culling. Slow; for parity experiments. */
+};
+
+typedef struct rtx_stats {
+    uint64_t rays_primary;    /* get_nearest_hit calls from render_tile's trace */
+    uint64_t rays_reflect;    /* mirror reflection rays (renderer.rs:164) */
+    uint64_t rays_gloss;      /* glossy reflection rays (renderer.rs:158-161) */
+    uint64_t rays_refract;    /* transmission rays incl. total internal reflection (renderer.rs:183) */
+    uint64_t rays_shadow;     /* shadow tries (renderer.rs:198) */
+    double ms_total;          /* wall time of the call, host clock */
+    double ms_device;         /* first kernel start -> last kernel end, HIP events */
+    double ms_closest;        /* sum of trace_closest+shade kernel durations, HIP events */
+    double ms_shadow;         /* sum of trace_shadow kernel durations, HIP events */
+    uint32_t launches_closest;
+    uint32_t launches_shadow;
+    uint64_t peak_pool_rays;
+    uint64_t reserved[4];
+} rtx_stats;
+
+typedef struct rtx_scene_info {
+    int32_t n_finite;         /* prims in the octree */
+    int32_t n_infinite;       /* planes */
+    int32_t octree_depth;     /* round(1.2 ln N / ln 8), octree.rs:29 (clamped to >= 0 for reporting) */
+    int32_t n_nodes;
+    int32_t n_interior;
+    int64_t n_leaf_entries;   /* sum of leaf_data lengths = N x duplication factor */
+    int32_t max_leaf_entries;
+    int32_t all_opaque;       /* 1 if every material's transmission() is exactly (0,0,0) */
+    int64_t device_bytes;     /* bytes uploaded for the scene */
+    double root_min[3], root_max[3];
+} rtx_scene_info;
+
+typedef struct rtx_scene rtx_scene;
+
+/* Replaces the scene half of the seam: what `Arc<Scene>` is to Renderer::render
+ * (renderer.rs:30, main.rs:117).  Builds the octree exactly as Octree::from_iter does
+ * (octree.rs:15-43, 64-133), linearises it and uploads everything to HIP device `device`. */
+rtx_status rtx_scene_create(const rtx_scene_desc *desc, int32_t device, rtx_scene **out);
+
+/* Drop for Arc<Scene>. NULL is a no-op. */
+rtx_status rtx_scene_destroy(rtx_scene *scene);
+
+rtx_status rtx_scene_get_info(const rtx_scene *scene, rtx_scene_info *info);
+
+/* Replaces Renderer::render (renderer.rs:30-65): renders the frame seen by `camera` and
+ * writes image_width*image_height RGBA8 pixels, row-major, row 0 = top of the image
+ * (Surface.buffer, surface.rs:18-25; abs_y = H-1-row, renderer.rs:73), alpha = 255
+ * (ColorRGBA::new_rgb, colorrgba.rs:88-90).  rgba_out / primary_prim_id_out are HOST
+ * buffers; primary_prim_id_out (int32 per pixel: prim id hit by sub-sample (0,0), -1 = miss)
+ * and stats may be NULL.  image_height must be a multiple of 8 (the reference underflows
+ * otherwise, renderer.rs:73). */
+rtx_status rtx_render(rtx_scene *scene, const rtx_camera *camera, const rtx_options *options,
+                      uint8_t *rgba_out, int32_t *primary_prim_id_out, rtx_stats *stats);
+
+/* Same, but the outputs are DEVICE pointers on the scene's device and the work is enqueued on
+ * `stream` (a hipStream_t passed as void*, NULL = default stream).  The call returns after the
+ * last kernel has been enqueued and the pool bookkeeping it needs has completed; the caller
+ * synchronises the stream before reading the outputs.  This is the entry point bench.py and
+ * the multi-GPU gather use: nothing crosses PCIe inside it. */
+rtx_status rtx_render_device(rtx_scene *scene, const rtx_camera *camera, const rtx_options *options,
+                             void *rgba_out_dev, void *primary_prim_id_out_dev, void *stream,
+                             rtx_stats *stats);
+
+/* Replaces Ray::get_nearest_hit (src/raytracer/ray.rs:44-66) for a batch of n rays given as
+ * host arrays origin[n][3], direction[n][3] (directions as the caller has them; the reference
+ * passes unit vectors).  Writes prim_id_out[n] (-1 = None) and t_out[n] (+inf for a miss).
+ * Used by the parity tests to compare hit ids / t bit for bit with the oracle. */
+rtx_status rtx_nearest_hits(rtx_scene *scene, int64_t n, const double *origin, const double *direction,
+                            int32_t *prim_id_out, double *t_out);
+
+/* Replaces the candidate fold in Renderer::shadow_intensity (renderer.rs:203-217) for a batch
+ * of n shadow feelers from origin[i] towards target[i] (host arrays [n][3]): shadow_out[n][3]
+ * is the product of transmission() over all occluders, duplicates included. */
+rtx_status rtx_shadow_products(rtx_scene *scene, int64_t n, const double *origin, const double *target,
+                               double *shadow_out);
+
+const char *rtx_strerror(rtx_status status);
+/* Last error text recorded by this thread (HIP error strings, limit details). Never NULL. */
+const char *rtx_last_error(void);
+/* "rtx <version> gfx950 ..." */
+const char *rtx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

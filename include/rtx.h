@@ -256,6 +256,14 @@ rtx_status rtx_nearest_hits(rtx_scene *scene, int64_t n, const double *origin, c
 rtx_status rtx_shadow_products(rtx_scene *scene, int64_t n, const double *origin, const double *target,
                                double *shadow_out);
 
+/* Diagnostic, needs no device: the octree rtx_scene_create builds for `desc` (Octree::from_iter,
+ * octree.rs:15-43), dumped in DFS pre-order with children 0..7: per node 6 doubles (bbox min,
+ * max) and 2 ints (number of children: 0 or 8, number of leaf entries); entries_out receives
+ * the leaf entries' prim ids in the same order.  depth is octree.rs:29's value (i32::MIN for an
+ * empty scene).  Pass NULL for the three arrays to query the sizes only. */
+rtx_status rtx_octree_dump(const rtx_scene_desc *desc, int32_t *depth, int64_t *n_nodes, int64_t *n_entries,
+                           double *bbox_out, int32_t *shape_out, int32_t *entries_out);
+
 const char *rtx_strerror(rtx_status status);
 /* Last error text recorded by this thread (HIP error strings, limit details). Never NULL. */
 const char *rtx_last_error(void);

@@ -1,0 +1,785 @@
+// rtx_api.cpp — the C ABI of include/rtx.h: scene flattening + octree build on the host,
+// upload, and the wavefront orchestration of the gfx950 kernels in rtx_kernels.hip.
+//
+// There is no CPU rendering path in this library: without a HIP device every entry point
+// that renders fails with RTX_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rtx_device.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+rtx_status fail(rtx_status st, const std::string &msg) {
+    g_last_error = msg;
+    return st;
+}
+#define HIPCHECK(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------- host octree
+// Octree::from_iter + OctreeNode::{subdivide,insert} (raytracer/octree.rs:15-43, 64-133),
+// with index-linked nodes instead of nested Vecs: the 8 children of a node are allocated
+// contiguously at subdivision time, which is exactly the layout the device wants.
+struct HBox {
+    double mn[3], mx[3];
+};
+struct HNode {
+    HBox bbox;
+    int depth;
+    int first_child = -1;
+    std::vector<int> entries;   // leaf_data indices; the entry's bbox is the prim's own bbox
+};
+bool overlaps(const HBox &a, const HBox &o) {                      // geometry/bbox.rs:167-173
+    bool x = a.mx[0] >= o.mn[0] && a.mn[0] <= o.mx[0];
+    bool y = a.mx[1] >= o.mn[1] && a.mn[1] <= o.mx[1];
+    bool z = a.mx[2] >= o.mn[2] && a.mn[2] <= o.mx[2];
+    return x && y && z;
+}
+struct HostOctree {
+    std::vector<HNode> nodes;
+    std::vector<HBox> prim_box;   // finite prims, insertion order
+    int depth = 0;
+
+    void subdivide(int ni) {                                       // octree.rs:75-98
+        int first = (int)nodes.size();
+        HBox b = nodes[ni].bbox;
+        int d = nodes[ni].depth;
+        for (unsigned x = 0; x < 2; ++x)
+            for (unsigned y = 0; y < 2; ++y)
+                for (unsigned z = 0; z < 2; ++z) {
+                    double lx = b.mx[0] - b.mn[0], ly = b.mx[1] - b.mn[1], lz = b.mx[2] - b.mn[2];
+                    HNode ch;
+                    ch.bbox.mn[0] = b.mn[0] + (double)x * lx / 2.0;
+                    ch.bbox.mn[1] = b.mn[1] + (double)y * ly / 2.0;
+                    ch.bbox.mn[2] = b.mn[2] + (double)z * lz / 2.0;
+                    ch.bbox.mx[0] = b.mx[0] - (double)(1 - x) * lx / 2.0;
+                    ch.bbox.mx[1] = b.mx[1] - (double)(1 - y) * ly / 2.0;
+                    ch.bbox.mx[2] = b.mx[2] - (double)(1 - z) * lz / 2.0;
+                    ch.depth = d - 1;
+                    nodes.push_back(std::move(ch));
+                }
+        nodes[ni].first_child = first;
+    }
+    void insert(int ni, int index) {                               // octree.rs:101-128
+        if (nodes[ni].depth <= 0) {
+            nodes[ni].entries.push_back(index);
+            return;
+        }
+        bool leaf = nodes[ni].first_child < 0;
+        if (leaf && nodes[ni].entries.empty()) {
+            nodes[ni].entries.push_back(index);
+            return;
+        }
+        if (leaf && nodes[ni].entries.size() == 1) {
+            subdivide(ni);
+            int old = nodes[ni].entries[0];
+            nodes[ni].entries.clear();
+            insert(ni, old);
+        }
+        int first = nodes[ni].first_child;
+        for (int c = 0; c < 8; ++c)
+            if (overlaps(nodes[first + c].bbox, prim_box[index])) insert(first + c, index);
+    }
+    void build() {                                                 // octree.rs:15-43
+        HBox bounds{{0, 0, 0}, {0, 0, 0}};                         // BBox::zero() when empty
+        for (size_t i = 0; i < prim_box.size(); ++i) {             // BBox::from_union, bbox.rs:85-97
+            const HBox &p = prim_box[i];
+            if (i == 0) bounds = p;
+            else
+                for (int a = 0; a < 3; ++a) {
+                    bounds.mn[a] = std::fmin(bounds.mn[a], p.mn[a]);
+                    bounds.mx[a] = std::fmax(bounds.mx[a], p.mx[a]);
+                }
+        }
+        double dd = std::round(1.2 * (std::log((double)prim_box.size()) / std::log(8.0)));
+        // `as i32` saturates (N = 0 gives -inf -> i32::MIN: the root stays a leaf)
+        depth = dd != dd ? 0 : (dd <= -2147483648.0 ? INT32_MIN : (dd >= 2147483647.0 ? INT32_MAX : (int)dd));
+        HNode root;
+        root.bbox = bounds;
+        root.depth = depth;
+        nodes.clear();
+        nodes.push_back(std::move(root));
+        for (size_t i = 0; i < prim_box.size(); ++i) insert(0, (int)i);
+    }
+    bool nonempty(int ni, std::vector<int8_t> &memo) const {
+        if (memo[ni] >= 0) return memo[ni] != 0;
+        bool ne = !nodes[ni].entries.empty();
+        if (nodes[ni].first_child >= 0)
+            for (int c = 0; c < 8; ++c) ne = nonempty(nodes[ni].first_child + c, memo) || ne;
+        memo[ni] = ne ? 1 : 0;
+        return ne;
+    }
+};
+
+// Flattened, validated view of an rtx_scene_desc with prims split by finiteness.
+struct Flat {
+    std::vector<int> fin_kind, fin_index;     // finite prims in insertion order
+    std::vector<int> inf_index;               // planes in insertion order
+    HostOctree oct;
+};
+
+rtx_status flatten(const rtx_scene_desc *d, Flat &fl) {
+    if (!d) return fail(RTX_ERR_INVALID_ARGUMENT, "desc is NULL");
+    if (d->n_spheres < 0 || d->n_planes < 0 || d->n_triangles < 0 || d->n_materials < 0 || d->n_textures < 0 ||
+        d->n_images < 0 || d->n_lights < 0)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "negative count in rtx_scene_desc");
+    long long total = (long long)d->n_spheres + d->n_planes + d->n_triangles;
+    if ((d->order_kind == nullptr) != (d->order_index == nullptr))
+        return fail(RTX_ERR_INVALID_ARGUMENT, "order_kind and order_index must both be given or both be NULL");
+    if (d->order_kind && d->n_prims != total) return fail(RTX_ERR_INVALID_ARGUMENT, "n_prims != n_spheres + n_planes + n_triangles");
+    if ((d->n_spheres && (!d->sphere_center || !d->sphere_radius || !d->sphere_material)) ||
+        (d->n_planes && (!d->plane_abcd || !d->plane_material)) ||
+        (d->n_triangles && (!d->tri_vertices || !d->tri_normals || !d->tri_uv || !d->tri_material)) ||
+        (d->n_materials && !d->materials) || (d->n_textures && !d->textures) || (d->n_images && !d->images) ||
+        (d->n_lights && !d->lights))
+        return fail(RTX_ERR_INVALID_ARGUMENT, "NULL array with a non-zero count");
+    if (d->n_lights > RTX_MAX_LIGHTS) return fail(RTX_ERR_LIMIT, "more than 16 lights");
+    auto mat_ok = [&](int m) { return m >= 0 && m < d->n_materials; };
+    for (int i = 0; i < d->n_spheres; ++i) if (!mat_ok(d->sphere_material[i])) return fail(RTX_ERR_INVALID_ARGUMENT, "sphere material out of range");
+    for (int i = 0; i < d->n_planes; ++i) if (!mat_ok(d->plane_material[i])) return fail(RTX_ERR_INVALID_ARGUMENT, "plane material out of range");
+    for (int i = 0; i < d->n_triangles; ++i) if (!mat_ok(d->tri_material[i])) return fail(RTX_ERR_INVALID_ARGUMENT, "triangle material out of range");
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rtx_material &m = d->materials[i];
+        if (m.kind < RTX_MAT_COOK_TORRANCE || m.kind > RTX_MAT_FLAT) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown material kind");
+        if (m.texture >= d->n_textures) return fail(RTX_ERR_INVALID_ARGUMENT, "material texture out of range");
+    }
+    for (int i = 0; i < d->n_textures; ++i) {
+        const rtx_texture &t = d->textures[i];
+        if (t.kind < RTX_TEX_CHECKER || t.kind > RTX_TEX_IMAGE) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown texture kind");
+        if (t.kind == RTX_TEX_IMAGE && (t.image < 0 || t.image >= d->n_images)) return fail(RTX_ERR_INVALID_ARGUMENT, "texture image out of range");
+    }
+    for (int i = 0; i < d->n_images; ++i)
+        if (d->images[i].width <= 0 || d->images[i].height <= 0 || !d->images[i].rgba) return fail(RTX_ERR_INVALID_ARGUMENT, "bad image");
+    if (d->skybox_image[0] >= 0)
+        for (int f = 0; f < 6; ++f)
+            if (d->skybox_image[f] < 0 || d->skybox_image[f] >= d->n_images) return fail(RTX_ERR_INVALID_ARGUMENT, "skybox image out of range");
+
+    std::vector<uint8_t> seen_s((size_t)d->n_spheres, 0), seen_p((size_t)d->n_planes, 0), seen_t((size_t)d->n_triangles, 0);
+    for (long long k = 0; k < total; ++k) {
+        int kind, idx;
+        if (d->order_kind) { kind = d->order_kind[k]; idx = d->order_index[k]; }
+        else if (k < d->n_spheres) { kind = RTX_PRIM_SPHERE; idx = (int)k; }
+        else if (k < (long long)d->n_spheres + d->n_triangles) { kind = RTX_PRIM_TRIANGLE; idx = (int)(k - d->n_spheres); }
+        else { kind = RTX_PRIM_PLANE; idx = (int)(k - d->n_spheres - d->n_triangles); }
+        std::vector<uint8_t> *seen = kind == RTX_PRIM_SPHERE ? &seen_s : kind == RTX_PRIM_PLANE ? &seen_p : kind == RTX_PRIM_TRIANGLE ? &seen_t : nullptr;
+        if (!seen || idx < 0 || (size_t)idx >= seen->size() || (*seen)[(size_t)idx]) return fail(RTX_ERR_INVALID_ARGUMENT, "order_kind/order_index is not a permutation of the prims");
+        (*seen)[(size_t)idx] = 1;
+        if (kind == RTX_PRIM_PLANE) {                              // plane.rs:19-23: no bounding box
+            fl.inf_index.push_back(idx);
+            continue;
+        }
+        HBox b;
+        if (kind == RTX_PRIM_SPHERE) {                             // sphere.rs:18-33
+            const double *c = d->sphere_center + (size_t)idx * 3;
+            double r = d->sphere_radius[idx];
+            for (int a = 0; a < 3; ++a) { b.mn[a] = c[a] - r; b.mx[a] = c[a] + r; }
+        } else {                                                   // triangle.rs:102-106
+            const double *v = d->tri_vertices + (size_t)idx * 9;
+            for (int a = 0; a < 3; ++a) {
+                b.mn[a] = std::fmin(std::fmin(v[a], v[3 + a]), v[6 + a]);
+                b.mx[a] = std::fmax(std::fmax(v[a], v[3 + a]), v[6 + a]);
+            }
+        }
+        fl.fin_kind.push_back(kind);
+        fl.fin_index.push_back(idx);
+        fl.oct.prim_box.push_back(b);
+    }
+    fl.oct.build();
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------- workspace
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind = 0;
+};
+
+struct Work {
+    DPool pool{};
+    DShadowQ sq{};
+    DCounters *d_counters = nullptr;
+    DCounters *h_up = nullptr, *h_back = nullptr;   // pinned
+    double *acc = nullptr;
+    size_t acc_cap = 0;       // samples
+    uint8_t *out_rgba = nullptr;
+    int32_t *out_ids = nullptr;
+    size_t out_pixels = 0;
+    std::vector<hipEvent_t> events;
+};
+
+template <class T>
+rtx_status dev_alloc(T **p, size_t n) {
+    HIPCHECK(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return RTX_OK;
+}
+
+} // namespace
+
+struct rtx_scene {
+    int device = 0;
+    DScene d{};
+    std::vector<void *> allocs;
+    rtx_scene_info info{};
+    std::vector<rtx_light> lights;
+    bool any_reflective = false, any_refractive = false, any_glossy = false;
+    Work w;
+};
+
+namespace {
+
+template <class T>
+rtx_status upload(rtx_scene *s, const std::vector<T> &v, const T **out) {
+    T *p = nullptr;
+    size_t n = std::max<size_t>(v.size(), 1);
+    HIPCHECK(hipMalloc((void **)&p, n * sizeof(T)));
+    s->allocs.push_back(p);
+    HIPCHECK(hipMemset(p, 0, n * sizeof(T)));
+    if (!v.empty()) HIPCHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    s->info.device_bytes += (int64_t)(n * sizeof(T));
+    *out = p;
+    return RTX_OK;
+}
+
+void free_work(Work &w) {
+    if (w.pool.f) hipFree(w.pool.f);
+    if (w.pool.key) hipFree(w.pool.key);
+    if (w.pool.sample) hipFree(w.pool.sample);
+    if (w.pool.flags) hipFree(w.pool.flags);
+    if (w.sq.f) hipFree(w.sq.f);
+    if (w.sq.key) hipFree(w.sq.key);
+    if (w.sq.sample) hipFree(w.sq.sample);
+    if (w.d_counters) hipFree(w.d_counters);
+    if (w.h_up) hipHostFree(w.h_up);
+    if (w.h_back) hipHostFree(w.h_back);
+    if (w.acc) hipFree(w.acc);
+    if (w.out_rgba) hipFree(w.out_rgba);
+    if (w.out_ids) hipFree(w.out_ids);
+    for (hipEvent_t e : w.events) hipEventDestroy(e);
+    w = Work();
+}
+
+rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n_samples) {
+    Work &w = s->w;
+    if (w.pool.cap < pool_cap) {
+        if (w.pool.f) { hipFree(w.pool.f); hipFree(w.pool.key); hipFree(w.pool.sample); hipFree(w.pool.flags); w.pool = DPool(); }
+        rtx_status st;
+        if ((st = dev_alloc(&w.pool.f, (size_t)pool_cap * 9))) return st;
+        if ((st = dev_alloc(&w.pool.key, pool_cap))) return st;
+        if ((st = dev_alloc(&w.pool.sample, pool_cap))) return st;
+        if ((st = dev_alloc(&w.pool.flags, pool_cap))) return st;
+        w.pool.cap = pool_cap;
+    }
+    size_t nl = std::max<size_t>(s->lights.size(), 1);
+    if (w.sq.cap < batch) {
+        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); w.sq = DShadowQ(); }
+        rtx_status st;
+        if ((st = dev_alloc(&w.sq.f, nl * 6 * (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq.key, nl * (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq.sample, nl * (size_t)batch))) return st;
+        w.sq.cap = batch;
+    }
+    if (!w.d_counters) {
+        rtx_status st;
+        if ((st = dev_alloc(&w.d_counters, 1))) return st;
+        HIPCHECK(hipHostMalloc((void **)&w.h_up, sizeof(DCounters), hipHostMallocDefault));
+        HIPCHECK(hipHostMalloc((void **)&w.h_back, sizeof(DCounters), hipHostMallocDefault));
+    }
+    if (w.acc_cap < n_samples) {
+        if (w.acc) { hipFree(w.acc); w.acc = nullptr; w.acc_cap = 0; }
+        rtx_status st;
+        if ((st = dev_alloc(&w.acc, n_samples * 3))) return st;
+        w.acc_cap = n_samples;
+    }
+    return RTX_OK;
+}
+
+// Camera::new -> update_eye_vector / update_internal_sizes (scene/camera.rs:26-50, 88-105)
+void fill_camera(DFrame &fr, const rtx_camera &c) {
+    const double PI = 3.14159265358979323846264338327950288;
+    double e[3] = {c.look_at[0] - c.position[0], c.look_at[1] - c.position[1], c.look_at[2] - c.position[2]};
+    double l = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int a = 0; a < 3; ++a) {
+        fr.pos[a] = c.position[a];
+        fr.up[a] = c.up[a];
+        fr.eye[a] = e[a] / l;
+    }
+    fr.right[0] = fr.eye[1] * fr.up[2] - fr.eye[2] * fr.up[1];     // eye.cross(up), NOT normalised
+    fr.right[1] = fr.eye[2] * fr.up[0] - fr.eye[0] * fr.up[2];
+    fr.right[2] = fr.eye[0] * fr.up[1] - fr.eye[1] * fr.up[0];
+    double fov_rad = c.fov_deg * (PI / 180.0);
+    double ratio = (double)c.image_height / (double)c.image_width;
+    fr.half_width = std::tan(fov_rad);                             // the full angle, camera.rs:97
+    fr.half_height = fr.half_width * ratio;
+    double camera_width = fr.half_width * 2.0, camera_height = fr.half_height * 2.0;
+    fr.pixel_width = camera_width / (double)(c.image_width - 1);
+    fr.pixel_height = camera_height / (double)(c.image_height - 1);
+}
+
+struct Seg {
+    uint32_t begin, end;
+};
+
+rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *d_rgba, int32_t *d_ids,
+                       hipStream_t stream, rtx_stats *stats) {
+    auto wall0 = std::chrono::steady_clock::now();
+    if (!s || !cam || !opt || !d_rgba) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (cam->image_width == 0 || cam->image_height == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "empty image");
+    if (cam->image_height % 8 != 0)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "image_height must be a multiple of 8 (renderer.rs:73 underflows otherwise)");
+    if (opt->reflect_depth > RTX_MAX_DEPTH || opt->refract_depth > RTX_MAX_DEPTH)
+        return fail(RTX_ERR_LIMIT, "reflect_depth / refract_depth above 4095");
+    if (opt->rng_mode > RTX_RNG_PHILOX) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown rng_mode");
+    uint32_t shard_count = opt->shard_count ? opt->shard_count : 1;
+    if (opt->shard_index >= shard_count) return fail(RTX_ERR_INVALID_ARGUMENT, "shard_index >= shard_count");
+    HIPCHECK(hipSetDevice(s->device));
+
+    DFrame fr{};
+    fill_camera(fr, *cam);
+    fr.W = cam->image_width; fr.H = cam->image_height;
+    fr.ps = opt->pixel_samples; fr.spp = opt->pixel_samples * opt->pixel_samples;
+    fr.inv_ps = 1.0 / (double)opt->pixel_samples;
+    fr.inv_spp = 1.0 / (double)(opt->pixel_samples * opt->pixel_samples);
+    fr.seed = opt->seed;
+    fr.tiles_x = (fr.W + 7) / 8;
+    fr.shard_index = opt->shard_index; fr.shard_count = shard_count;
+    uint32_t n_blocks = fr.H / 8;
+    fr.n_blocks_local = opt->shard_index < n_blocks ? (n_blocks - opt->shard_index + shard_count - 1) / shard_count : 0;
+    fr.reflect_depth = opt->reflect_depth; fr.refract_depth = opt->refract_depth;
+    fr.shadow_samples = opt->shadow_samples; fr.gloss_samples = opt->gloss_samples;
+    fr.rng_mode = opt->rng_mode; fr.frame = opt->frame; fr.flags = opt->flags;
+
+    uint64_t n_samples64 = (uint64_t)fr.n_blocks_local * fr.tiles_x * 64ull * fr.spp;
+    if (n_samples64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "more than 2^32 samples in one call");
+    uint32_t n_samples = (uint32_t)n_samples64;
+
+    uint32_t batch = opt->batch_rays ? opt->batch_rays : (4u << 20);
+    batch = std::max<uint32_t>(batch, RTX_BLOCK);
+    uint32_t fanout = 0;
+    if (s->any_reflective) fanout += s->any_glossy ? std::max<uint32_t>(1, opt->gloss_samples) : 1;
+    if (s->any_refractive) fanout += 1;
+    uint64_t pool_cap64 = opt->pool_rays ? opt->pool_rays : (uint64_t)batch * (fanout > 1 ? 16 : 2);
+    pool_cap64 = std::max<uint64_t>(pool_cap64, (uint64_t)batch * (1 + fanout));
+    if (pool_cap64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "ray pool above 2^32 rays");
+    uint32_t pool_cap = (uint32_t)pool_cap64;
+
+    rtx_status st = ensure_work(s, pool_cap, batch, n_samples);
+    if (st) return st;
+    Work &w = s->w;
+    size_t ev_used = 0;
+    auto next_event = [&](hipEvent_t *e) -> rtx_status {
+        if (ev_used == w.events.size()) {
+            hipEvent_t ne;
+            HIPCHECK(hipEventCreate(&ne));
+            w.events.push_back(ne);
+        }
+        *e = w.events[ev_used++];
+        return RTX_OK;
+    };
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    const bool timing = stats != nullptr;
+
+    // the depth test at the top of Renderer::trace (renderer.rs:106): no rays at all
+    bool trace_anything = opt->reflect_depth > 0 && opt->refract_depth > 0 && fr.spp > 0;
+
+    if (n_samples) HIPCHECK(hipMemsetAsync(w.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));
+    std::memset(w.h_up, 0, sizeof(DCounters));
+    HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, sizeof(DCounters), hipMemcpyHostToDevice, stream));
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    if (timing) {
+        if ((st = next_event(&ev_first))) return st;
+        HIPCHECK(hipEventRecord(ev_first, stream));
+    }
+
+    uint32_t launches_closest = 0, launches_shadow = 0;
+    uint64_t peak_pool = 0;
+    std::vector<Seg> segs;
+    uint32_t s_next = 0;
+    while (trace_anything) {
+        if (segs.empty()) {
+            if (s_next >= n_samples) break;
+            uint32_t cnt = std::min<uint32_t>(batch, n_samples - s_next);
+            rtxk_generate(stream, fr, w.pool, 0, s_next, cnt);
+            segs.push_back(Seg{0, cnt});
+            s_next += cnt;
+        }
+        Seg &top = segs.back();
+        uint32_t top_end = top.end;
+        uint32_t n = std::min<uint32_t>(batch, top.end - top.begin);
+        if (fanout > 0) {
+            uint64_t fit = (uint64_t)(pool_cap - top_end) / fanout;
+            if (fit < n) n = (uint32_t)fit;
+            if (n == 0) return fail(RTX_ERR_QUEUE_OVERFLOW, "ray pool exhausted; raise rtx_options.pool_rays");
+        }
+        uint32_t begin = top.end - n;
+        w.h_up->pool_tail = top_end;
+        w.h_up->overflow = 0;
+        for (int li = 0; li < RTX_MAX_LIGHTS; ++li) w.h_up->shadow_tail[li] = 0;
+        HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, offsetof(DCounters, rays), hipMemcpyHostToDevice, stream));
+        Span sp_c{nullptr, nullptr, 0};
+        if (timing) {
+            if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b))) return st;
+            HIPCHECK(hipEventRecord(sp_c.a, stream));
+        }
+        rtxk_trace(stream, s->d, fr, w.pool, begin, n, w.sq, w.d_counters, w.acc, d_ids);
+        ++launches_closest;
+        if (timing) {
+            HIPCHECK(hipEventRecord(sp_c.b, stream));
+            spans.push_back(sp_c);
+        }
+        HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        if (w.h_back->overflow) return fail(RTX_ERR_QUEUE_OVERFLOW, "device queue overflow");
+        top.end = begin;
+        if (top.begin == top.end) segs.pop_back();
+        uint32_t children = w.h_back->pool_tail - top_end;
+        if (children) segs.push_back(Seg{top_end, top_end + children});
+        peak_pool = std::max<uint64_t>(peak_pool, (uint64_t)top_end + children);
+
+        Span sp_s{nullptr, nullptr, 1};
+        bool any_shadow = false;
+        for (size_t li = 0; li < s->lights.size(); ++li) {
+            uint32_t groups = w.h_back->shadow_tail[li];
+            if (!groups) continue;
+            uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194
+            if (timing && !any_shadow) {
+                if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
+                HIPCHECK(hipEventRecord(sp_s.a, stream));
+            }
+            any_shadow = true;
+            rtxk_shadow(stream, s->d, fr, w.sq, (uint32_t)li, groups, tries, w.d_counters, w.acc);
+            ++launches_shadow;
+        }
+        if (timing && any_shadow) {
+            HIPCHECK(hipEventRecord(sp_s.b, stream));
+            spans.push_back(sp_s);
+        }
+    }
+    rtxk_resolve(stream, fr, w.acc, d_rgba);
+    HIPCHECK(hipGetLastError());
+
+    if (stats) {
+        if ((st = next_event(&ev_last))) return st;
+        HIPCHECK(hipEventRecord(ev_last, stream));
+        HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_primary = w.h_back->rays[RAY_PRIMARY];
+        stats->rays_reflect = w.h_back->rays[RAY_REFLECT];
+        stats->rays_gloss = w.h_back->rays[RAY_GLOSS];
+        stats->rays_refract = w.h_back->rays[RAY_REFRACT];
+        stats->rays_shadow = w.h_back->rays[RAY_SHADOW];
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, ev_first, ev_last));
+        stats->ms_device = ms;
+        for (const Span &sp : spans) {
+            HIPCHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
+            (sp.kind == 0 ? stats->ms_closest : stats->ms_shadow) += ms;
+        }
+        stats->launches_closest = launches_closest;
+        stats->launches_shadow = launches_shadow;
+        stats->peak_pool_rays = peak_pool;
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    return RTX_OK;
+}
+
+} // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene **out) {
+    if (!out) return fail(RTX_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    Flat fl;
+    rtx_status st = flatten(d, fl);
+    if (st) return st;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIPCHECK(hipSetDevice(device));
+
+    const HostOctree &oct = fl.oct;
+    int depth_for_stack = std::max(oct.depth, 0);
+    if (depth_for_stack > RTX_MAX_LEVELS) return fail(RTX_ERR_LIMIT, "octree deeper than 12 levels");
+    if (oct.nodes.size() >= (1u << 24)) return fail(RTX_ERR_LIMIT, "octree has 2^24 nodes or more");
+
+    std::unique_ptr<rtx_scene> s(new rtx_scene());
+    s->device = device;
+    auto cleanup = [&](rtx_status e) {
+        for (void *p : s->allocs) hipFree(p);
+        return e;
+    };
+
+    // prim records; prim id = rank among finite prims, planes after (rtx.h)
+    int n_fin = (int)fl.fin_kind.size();
+    std::vector<DTri> tris((size_t)d->n_triangles);
+    std::vector<DTriShade> shade((size_t)d->n_triangles);
+    std::vector<DSphere> spheres((size_t)d->n_spheres);
+    std::vector<DPlane> planes(fl.inf_index.size());
+    std::vector<int32_t> ref_of_prim((size_t)n_fin);
+    for (int i = 0; i < n_fin; ++i) {
+        int idx = fl.fin_index[(size_t)i];
+        if (fl.fin_kind[(size_t)i] == RTX_PRIM_TRIANGLE) {
+            DTri &t = tris[(size_t)idx];
+            std::memcpy(t.v, d->tri_vertices + (size_t)idx * 9, 9 * sizeof(double));
+            t.prim_id = i;
+            t.material = d->tri_material[idx];
+            DTriShade &sh = shade[(size_t)idx];
+            std::memcpy(sh.n, d->tri_normals + (size_t)idx * 9, 9 * sizeof(double));
+            std::memcpy(sh.uv, d->tri_uv + (size_t)idx * 6, 6 * sizeof(double));
+            sh.pad = 0.0;
+            ref_of_prim[(size_t)i] = idx;
+        } else {
+            DSphere &sp = spheres[(size_t)idx];
+            std::memcpy(sp.c, d->sphere_center + (size_t)idx * 3, 3 * sizeof(double));
+            sp.r = d->sphere_radius[idx];
+            sp.prim_id = i;
+            sp.material = d->sphere_material[idx];
+            sp.pad = 0.0;
+            ref_of_prim[(size_t)i] = ~idx;
+        }
+    }
+    for (size_t j = 0; j < fl.inf_index.size(); ++j) {
+        int idx = fl.inf_index[j];
+        DPlane &pl = planes[j];
+        std::memcpy(pl.abcd, d->plane_abcd + (size_t)idx * 4, 4 * sizeof(double));
+        pl.prim_id = n_fin + (int)j;
+        pl.material = d->plane_material[idx];
+        pl.pad = 0.0;
+    }
+    // nodes + leaf entries
+    std::vector<DNode> nodes(oct.nodes.size());
+    std::vector<int32_t> leaf_refs;
+    std::vector<int8_t> memo(oct.nodes.size(), -1);
+    int n_interior = 0, max_entries = 0;
+    for (size_t i = 0; i < oct.nodes.size(); ++i) {
+        const HNode &hn = oct.nodes[i];
+        DNode &dn = nodes[i];
+        for (int a = 0; a < 3; ++a) { dn.bmin[a] = hn.bbox.mn[a]; dn.bmax[a] = hn.bbox.mx[a]; }
+        dn.first_child = hn.first_child;
+        dn.entry_begin = (int32_t)leaf_refs.size();
+        dn.entry_count = (int32_t)hn.entries.size();
+        dn.child_mask = 0;
+        if (hn.first_child >= 0) {
+            ++n_interior;
+            for (int c = 0; c < 8; ++c)
+                if (oct.nonempty(hn.first_child + c, memo)) dn.child_mask |= 1u << c;
+        }
+        for (int e : hn.entries) leaf_refs.push_back(ref_of_prim[(size_t)e]);
+        max_entries = std::max(max_entries, (int)hn.entries.size());
+    }
+    // images -> one RGBA8 atlas
+    std::vector<DImage> images((size_t)d->n_images);
+    std::vector<uint8_t> atlas;
+    for (int i = 0; i < d->n_images; ++i) {
+        images[(size_t)i].w = d->images[i].width;
+        images[(size_t)i].h = d->images[i].height;
+        images[(size_t)i].offset = (int64_t)atlas.size();
+        size_t nb = (size_t)d->images[i].width * (size_t)d->images[i].height * 4;
+        atlas.insert(atlas.end(), d->images[i].rgba, d->images[i].rgba + nb);
+        while (atlas.size() % 16) atlas.push_back(0);
+    }
+    std::vector<rtx_material> materials(d->materials, d->materials + d->n_materials);
+    std::vector<rtx_texture> textures(d->textures, d->textures + d->n_textures);
+    s->lights.assign(d->lights, d->lights + d->n_lights);
+    bool all_opaque = true;
+    for (const rtx_material &m : materials) {
+        if (m.kind == RTX_MAT_FLAT) continue;
+        if (m.transmission[0] != 0.0 || m.transmission[1] != 0.0 || m.transmission[2] != 0.0) all_opaque = false;
+        if (m.k_sg > 0.0) s->any_reflective = true;
+        if (m.k_tg > 0.0) s->any_refractive = true;
+        if (m.glossiness > 2.220446049250313e-16) s->any_glossy = true;
+    }
+
+    DScene &ds = s->d;
+    if ((st = upload(s.get(), nodes, &ds.nodes)) || (st = upload(s.get(), leaf_refs, &ds.leaf_refs)) ||
+        (st = upload(s.get(), tris, &ds.tris)) || (st = upload(s.get(), shade, &ds.tri_shade)) ||
+        (st = upload(s.get(), spheres, &ds.spheres)) || (st = upload(s.get(), planes, &ds.planes)) ||
+        (st = upload(s.get(), materials, &ds.materials)) || (st = upload(s.get(), textures, &ds.textures)) ||
+        (st = upload(s.get(), images, &ds.images)) || (st = upload(s.get(), atlas, &ds.atlas)) ||
+        (st = upload(s.get(), s->lights, &ds.lights)))
+        return cleanup(st);
+    ds.n_planes = (int32_t)planes.size();
+    ds.n_lights = d->n_lights;
+    ds.has_skybox = d->skybox_image[0] >= 0 ? 1 : 0;
+    ds.all_opaque = all_opaque ? 1 : 0;
+    for (int f = 0; f < 6; ++f) ds.skybox[f] = d->skybox_image[f];
+    for (int a = 0; a < 3; ++a) ds.background[a] = d->background[a];
+
+    rtx_scene_info &info = s->info;
+    info.n_finite = n_fin;
+    info.n_infinite = (int32_t)planes.size();
+    info.octree_depth = depth_for_stack;
+    info.n_nodes = (int32_t)nodes.size();
+    info.n_interior = n_interior;
+    info.n_leaf_entries = (int64_t)leaf_refs.size();
+    info.max_leaf_entries = max_entries;
+    info.all_opaque = ds.all_opaque;
+    for (int a = 0; a < 3; ++a) { info.root_min[a] = nodes[0].bmin[a]; info.root_max[a] = nodes[0].bmax[a]; }
+    *out = s.release();
+    return RTX_OK;
+}
+
+rtx_status rtx_scene_destroy(rtx_scene *s) {
+    if (!s) return RTX_OK;
+    hipSetDevice(s->device);
+    free_work(s->w);
+    for (void *p : s->allocs) hipFree(p);
+    delete s;
+    return RTX_OK;
+}
+
+rtx_status rtx_scene_get_info(const rtx_scene *s, rtx_scene_info *info) {
+    if (!s || !info) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *info = s->info;
+    return RTX_OK;
+}
+
+rtx_status rtx_render_device(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, void *rgba_out_dev,
+                             void *primary_prim_id_out_dev, void *stream, rtx_stats *stats) {
+    return render_impl(s, cam, opt, (uint8_t *)rgba_out_dev, (int32_t *)primary_prim_id_out_dev, (hipStream_t)stream, stats);
+}
+
+rtx_status rtx_render(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *rgba_out,
+                      int32_t *primary_prim_id_out, rtx_stats *stats) {
+    if (!s || !cam || !opt || !rgba_out) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIPCHECK(hipSetDevice(s->device));
+    size_t n_pix = (size_t)cam->image_width * cam->image_height;
+    Work &w = s->w;
+    if (w.out_pixels < n_pix) {
+        if (w.out_rgba) hipFree(w.out_rgba);
+        if (w.out_ids) hipFree(w.out_ids);
+        w.out_rgba = nullptr; w.out_ids = nullptr; w.out_pixels = 0;
+        rtx_status st;
+        if ((st = dev_alloc(&w.out_rgba, n_pix * 4)) || (st = dev_alloc(&w.out_ids, n_pix))) return st;
+        w.out_pixels = n_pix;
+    }
+    rtx_status st = render_impl(s, cam, opt, w.out_rgba, primary_prim_id_out ? w.out_ids : nullptr, nullptr, stats);
+    if (st) return st;
+    HIPCHECK(hipDeviceSynchronize());
+    uint32_t shard_count = opt->shard_count ? opt->shard_count : 1;
+    size_t W = cam->image_width;
+    for (uint32_t b = opt->shard_index; b < cam->image_height / 8; b += shard_count) {   // only the rows this shard owns
+        size_t off = (size_t)b * 8 * W;
+        HIPCHECK(hipMemcpy(rgba_out + off * 4, w.out_rgba + off * 4, 8 * W * 4, hipMemcpyDeviceToHost));
+        if (primary_prim_id_out)
+            HIPCHECK(hipMemcpy(primary_prim_id_out + off, w.out_ids + off, 8 * W * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return RTX_OK;
+}
+
+rtx_status rtx_nearest_hits(rtx_scene *s, int64_t n, const double *origin, const double *direction, int32_t *prim_id_out,
+                            double *t_out) {
+    if (!s || n < 0 || (n && (!origin || !direction || !prim_id_out || !t_out))) return fail(RTX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(s->device));
+    double *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int32_t *d_id = nullptr;
+    rtx_status st = RTX_OK;
+    auto done = [&](rtx_status e) {
+        hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_id);
+        return e;
+    };
+    if ((st = dev_alloc(&d_o, (size_t)n * 3)) || (st = dev_alloc(&d_d, (size_t)n * 3)) || (st = dev_alloc(&d_t, (size_t)n)) ||
+        (st = dev_alloc(&d_id, (size_t)n)))
+        return done(st);
+    if (hipMemcpy(d_o, origin, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_d, direction, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(RTX_ERR_HIP, "upload failed"));
+    rtxk_nearest(nullptr, s->d, n, d_o, d_d, d_id, d_t, 0);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return done(fail(RTX_ERR_HIP, "k_nearest failed"));
+    if (hipMemcpy(prim_id_out, d_id, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(t_out, d_t, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(RTX_ERR_HIP, "download failed"));
+    return done(RTX_OK);
+}
+
+rtx_status rtx_shadow_products(rtx_scene *s, int64_t n, const double *origin, const double *target, double *shadow_out) {
+    if (!s || n < 0 || (n && (!origin || !target || !shadow_out))) return fail(RTX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(s->device));
+    double *d_o = nullptr, *d_s = nullptr, *d_out = nullptr;
+    rtx_status st = RTX_OK;
+    auto done = [&](rtx_status e) {
+        hipFree(d_o); hipFree(d_s); hipFree(d_out);
+        return e;
+    };
+    if ((st = dev_alloc(&d_o, (size_t)n * 3)) || (st = dev_alloc(&d_s, (size_t)n * 3)) || (st = dev_alloc(&d_out, (size_t)n * 3)))
+        return done(st);
+    if (hipMemcpy(d_o, origin, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_s, target, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(RTX_ERR_HIP, "upload failed"));
+    rtxk_shadow_products(nullptr, s->d, n, d_o, d_s, d_out);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return done(fail(RTX_ERR_HIP, "k_shadow_products failed"));
+    if (hipMemcpy(shadow_out, d_out, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(RTX_ERR_HIP, "download failed"));
+    return done(RTX_OK);
+}
+
+// Diagnostic, no device needed: the octree rtx_scene_create would build, in DFS pre-order
+// (children 0..7): per node 6 doubles (bbox min, max), 2 ints (n_children, n_entries); the
+// entries are finite-prim ids.  Pass NULL arrays to get the sizes only.
+rtx_status rtx_octree_dump(const rtx_scene_desc *d, int32_t *depth, int64_t *n_nodes, int64_t *n_entries, double *bbox_out,
+                           int32_t *shape_out, int32_t *entries_out) {
+    Flat fl;
+    rtx_status st = flatten(d, fl);
+    if (st) return st;
+    const HostOctree &oct = fl.oct;
+    int64_t ne = 0;
+    for (const HNode &n : oct.nodes) ne += (int64_t)n.entries.size();
+    if (depth) *depth = oct.depth;
+    if (n_nodes) *n_nodes = (int64_t)oct.nodes.size();
+    if (n_entries) *n_entries = ne;
+    if (!bbox_out || !shape_out || !entries_out) return RTX_OK;
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        int ni = stack.back();
+        stack.pop_back();
+        const HNode &n = oct.nodes[(size_t)ni];
+        for (int a = 0; a < 3; ++a) *bbox_out++ = n.bbox.mn[a];
+        for (int a = 0; a < 3; ++a) *bbox_out++ = n.bbox.mx[a];
+        *shape_out++ = n.first_child >= 0 ? 8 : 0;
+        *shape_out++ = (int32_t)n.entries.size();
+        for (int e : n.entries) *entries_out++ = e;
+        if (n.first_child >= 0)
+            for (int c = 7; c >= 0; --c) stack.push_back(n.first_child + c);
+    }
+    return RTX_OK;
+}
+
+const char *rtx_strerror(rtx_status st) {
+    switch (st) {
+    case RTX_OK: return "ok";
+    case RTX_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RTX_ERR_NO_DEVICE: return "no HIP device";
+    case RTX_ERR_HIP: return "HIP runtime error";
+    case RTX_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case RTX_ERR_LIMIT: return "scene or options exceed a documented limit";
+    case RTX_ERR_QUEUE_OVERFLOW: return "ray pool overflow";
+    default: return "unknown status";
+    }
+}
+const char *rtx_last_error(void) { return g_last_error.c_str(); }
+const char *rtx_version(void) { return "rtx 0.1 gfx950 f64 wavefront"; }
+
+} // extern "C"

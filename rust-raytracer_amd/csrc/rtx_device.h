@@ -1,0 +1,134 @@
+// rtx_device.h — device-side data layout of the flattened scene and the wavefront queues.
+// Shared by rtx_api.cpp (host: build, upload, orchestration) and rtx_kernels.hip (gfx950 kernels).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rtx.h"
+
+#define RTX_MAX_LEVELS 12     // level stack entries per lane (octree depth <= 12)
+#define RTX_MAX_LIGHTS 16
+#define RTX_MAX_DEPTH 4095    // reflect/refract depth fits 12 bits of the ray flags
+#define RTX_BLOCK 256         // threads per workgroup = 4 wave64
+
+// One octree node (octree.rs:51-56) in 64 bytes = one half cache line: the node's own bbox
+// (children's boxes are re-derived in registers with the reference's expressions,
+// octree.rs:81-92), the index of its 8 contiguous children, its leaf entries.
+struct alignas(64) DNode {
+    double bmin[3];
+    double bmax[3];
+    int32_t first_child;   // -1: leaf
+    int32_t entry_begin;   // into leaf_refs
+    int32_t entry_count;
+    uint32_t child_mask;   // bit k (k = x*4+y*2+z, octree.rs:76-78): child k's subtree holds >= 1 entry
+};
+
+// Intersection record of a triangle: 3 vertices (triangle.rs:90) + ids, 80 B, 16-B aligned.
+struct alignas(16) DTri {
+    double v[9];
+    int32_t prim_id;
+    int32_t material;
+};
+// Shading record (fetched once per closest hit): vertex normals and UVs (triangle.rs:94-97).
+struct alignas(16) DTriShade {
+    double n[9];
+    double uv[6];
+    double pad;
+};
+struct alignas(16) DSphere {
+    double c[3];
+    double r;
+    int32_t prim_id;
+    int32_t material;
+    double pad;
+};
+struct alignas(16) DPlane {
+    double abcd[4];
+    int32_t prim_id;
+    int32_t material;
+    double pad;
+};
+struct DImage {
+    int32_t w, h;
+    int64_t offset; // byte offset of the RGBA8 pixels in the atlas
+};
+
+struct DScene {
+    const DNode *nodes;
+    const int32_t *leaf_refs;   // >= 0: triangle index, < 0: ~sphere index
+    const DTri *tris;
+    const DTriShade *tri_shade;
+    const DSphere *spheres;
+    const DPlane *planes;
+    const rtx_material *materials;
+    const rtx_texture *textures;
+    const DImage *images;
+    const uint8_t *atlas;
+    const rtx_light *lights;
+    int32_t n_planes;
+    int32_t n_lights;
+    int32_t has_skybox;
+    int32_t all_opaque;
+    int32_t skybox[6];
+    double background[3];
+};
+
+// Camera (camera.rs:26-50,88-105) + RenderOptions (renderer.rs:14-21) + sharding, by value.
+struct DFrame {
+    double pos[3], eye[3], right[3], up[3];
+    double half_width, half_height, pixel_width, pixel_height;
+    double inv_ps;        // 1.0 / pixel_samples          (renderer.rs:78)
+    double inv_spp;       // 1.0 / (pixel_samples^2)      (renderer.rs:95)
+    uint64_t seed;
+    uint32_t W, H, ps, spp;
+    uint32_t tiles_x;     // ceil(W / 8)
+    uint32_t shard_index, shard_count, n_blocks_local;
+    uint32_t reflect_depth, refract_depth, shadow_samples, gloss_samples;
+    uint32_t rng_mode, frame, flags, pad;
+};
+
+// Ray pool: SoA, `cap` rays. f holds 9 component planes (origin, direction, throughput).
+struct DPool {
+    double *f;
+    uint64_t *key;      // RNG path key of the trace() call this ray stands for
+    uint32_t *sample;   // primary sample the ray contributes to
+    uint32_t *flags;
+    uint32_t cap;
+};
+#define RAYF_REFLECT_SHIFT 0
+#define RAYF_REFRACT_SHIFT 12
+#define RAYF_DEPTH_MASK 0xFFFu
+#define RAYF_INSIDE (1u << 24)
+#define RAYF_TYPE_SHIFT 25
+#define RAYF_DEAD (1u << 31)
+enum { RAY_PRIMARY = 0, RAY_REFLECT = 1, RAY_GLOSS = 2, RAY_REFRACT = 3, RAY_SHADOW = 4 };
+
+// Shadow groups: one entry per (closest hit, light); the shadow kernel gives each of the
+// light's `tries` feelers its own lane.  f holds 6 planes per light: hit position, weight.
+struct DShadowQ {
+    double *f;          // [n_lights][6][cap]
+    uint64_t *key;      // [n_lights][cap]
+    uint32_t *sample;   // [n_lights][cap]
+    uint32_t cap;
+};
+
+struct DCounters {
+    uint32_t pool_tail;
+    uint32_t overflow;
+    uint32_t shadow_tail[RTX_MAX_LIGHTS];
+    unsigned long long rays[5];
+};
+
+// ---- launch wrappers implemented in rtx_kernels.hip (all enqueue on `stream`) -----------
+struct hipStreamOpaque;
+typedef void *rtx_stream_t;
+
+void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count);
+void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
+                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out);
+void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+                 uint32_t tries, DCounters *counters, double *acc);
+void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);
+void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *direction,
+                  int32_t *prim_id, double *t_out, uint32_t flags);
+void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
+                          double *out);

@@ -1,0 +1,982 @@
+// rtx_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the per-pixel trace loop.
+//
+// The reference's recursive Renderer::trace (src/raytracer/renderer.rs:105-247) is unrolled
+// into a wavefront of ray queues: one ray per lane, an iterative octree traversal whose
+// short per-lane level stack lives in LDS, shadow feelers fanned out to their own lanes,
+// children (reflection / gloss / transmission) appended to a ray pool with wave-aggregated
+// atomics, per-sample f64 accumulators fed by hardware f64 atomic adds.  No MFMA: nothing
+// here is a dense contraction.  All arithmetic is IEEE f64 in the reference's operation
+// order; the file is compiled with -ffp-contract=off so no a*b+c is ever fused (Rust never
+// fuses), which is what keeps hit ids and the EPSILON-level shadow "acne" bit-identical.
+//
+// Each device function cites the reference file:line it follows (paths relative to src/).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtx_device.h"
+
+namespace {
+
+#define DEV __device__ __forceinline__
+
+constexpr double F64_EPSILON = 2.220446049250313e-16;  // std::f64::EPSILON
+constexpr double EPSILON = F64_EPSILON * 10000.0;       // raytracer/renderer.rs:12
+constexpr double PI = 3.14159265358979323846264338327950288;
+constexpr double T_MIN = 0.000001;                      // raytracer/ray.rs:45
+DEV double inf() { return __longlong_as_double(0x7FF0000000000000LL); }
+
+// ------------------------------------------------------------------------------ vec3.rs
+struct V3 {
+    double x, y, z;
+};
+DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEV V3 scale(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }                   // vec3.rs:56
+DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                // vec3.rs:34
+DEV V3 cross(V3 a, V3 b) {                                                               // vec3.rs:38
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DEV double len(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }                 // vec3.rs:30
+DEV V3 unit(V3 a) {                                                                      // vec3.rs:46
+    double l = len(a);
+    return v3(a.x / l, a.y / l, a.z / l);
+}
+DEV V3 reflect(V3 v, V3 n) { return scale(n, 2.0 * dot(n, v)) - v; }                     // vec3.rs:70
+DEV bool refract(V3 v, V3 n, double ior, bool inside, V3 *out) {                         // vec3.rs:77-92
+    double n1, n2, n_dot_v;
+    V3 nn;
+    if (!inside) {
+        n1 = 1.0; n2 = ior; n_dot_v = dot(n, v); nn = n;
+    } else {
+        n1 = ior; n2 = 1.0; n_dot_v = -dot(n, v); nn = -n;
+    }
+    double ratio = n1 / n2;
+    double disc = 1.0 - ((ratio * ratio) * (1.0 - n_dot_v * n_dot_v));
+    if (disc < 0.0) return false;
+    *out = scale(v, -ratio) + scale(nn, ratio * n_dot_v - sqrt(disc));
+    return true;
+}
+// f64::max/min ignore a NaN operand exactly like fmax/fmin (vec3.rs:102-108)
+DEV double clamp01(double x) { return fmin(fmax(x, 0.0), 1.0); }
+
+// ------------------------------------------------------------------------------ RNG
+// Philox4x32-10 (Salmon et al. 2011), the build's own counter-based generator: the
+// reference's thread_rng() is OS-seeded and unreproducible (renderer.rs:69, spherelight.rs:14,
+// vec3.rs:113).  Spec in DESIGN.md §RNG; the oracle implements the same spec independently.
+DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+constexpr uint32_t TAG_ROOT = 0x52545831u, TAG_CHILD = 0x4348494Cu, TAG_DRAW = 0x44524157u;
+enum { STREAM_JITTER = 0, STREAM_LIGHT = 1, STREAM_GLOSS = 2 };
+enum { CODE_MIRROR = 1, CODE_TRANSMIT = 2, CODE_GLOSS0 = 16 };
+DEV uint64_t root_key(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sub) {
+    uint32_t o[4];
+    philox4x32_10(pixel, sub, frame, TAG_ROOT, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+}
+DEV uint64_t child_key(uint64_t parent, uint32_t code) {
+    uint32_t o[4];
+    philox4x32_10(code, 0, 0, TAG_CHILD, (uint32_t)parent, (uint32_t)(parent >> 32), o);
+    return (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+}
+DEV void draw2(uint32_t mode, uint64_t key, uint32_t stream, uint32_t i, uint32_t j, double *a, double *b) {
+    if (mode == RTX_RNG_CENTER) { *a = 0.5; *b = 0.5; return; }
+    uint32_t o[4];
+    philox4x32_10(stream, i, j, TAG_DRAW, (uint32_t)key, (uint32_t)(key >> 32), o);
+    uint64_t ua = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+    uint64_t ub = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
+    *a = (double)(ua >> 11) * (1.0 / 9007199254740992.0);
+    *b = (double)(ub >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------ raytracer/ray.rs:15-42
+struct Ray {
+    double ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    bool sx, sy, sz;
+    uint32_t flip; // child k = j ^ flip visits the octants near-to-far for j = 0..7
+};
+DEV Ray make_ray(V3 o, V3 d) {
+    Ray r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    r.ix = 1.0 / d.x; r.iy = 1.0 / d.y; r.iz = 1.0 / d.z;
+    r.sx = r.ix > 0.0; r.sy = r.iy > 0.0; r.sz = r.iz > 0.0;
+    r.flip = (r.sx ? 0u : 4u) | (r.sy ? 0u : 2u) | (r.sz ? 0u : 1u);
+    return r;
+}
+
+// BBox::intersects, geometry/bbox.rs:99-165, on precomputed slab distances.  Comparisons are
+// transcribed literally (a NaN keeps the old bound); t_min/t_max are handed back for the
+// near-to-far culling that the reference does not do.
+DEV bool slab_combine(double t_min, double t_max, double ty_min, double ty_max, double tz_min, double tz_max,
+                      double *t_near, double *t_far) {
+    if (t_min > ty_max || ty_min > t_max) return false;
+    if (ty_min > t_min) t_min = ty_min;
+    if (ty_max < t_max) t_max = ty_max;
+    if (t_min > tz_max || tz_min > t_max) return false;
+    if (tz_min > t_min) t_min = tz_min;
+    if (tz_max < t_max) t_max = tz_max;
+    *t_near = t_min;
+    *t_far = t_max;
+    return t_min < inf() && t_max > 0.0;
+}
+DEV bool slab(double minx, double miny, double minz, double maxx, double maxy, double maxz, const Ray &r,
+              double *t_near, double *t_far) {
+    double t_min = ((r.sx ? minx : maxx) - r.ox) * r.ix;
+    double t_max = ((r.sx ? maxx : minx) - r.ox) * r.ix;
+    double ty_min = ((r.sy ? miny : maxy) - r.oy) * r.iy;
+    double ty_max = ((r.sy ? maxy : miny) - r.oy) * r.iy;
+    double tz_min = ((r.sz ? minz : maxz) - r.oz) * r.iz;
+    double tz_max = ((r.sz ? maxz : minz) - r.oz) * r.iz;
+    return slab_combine(t_min, t_max, ty_min, ty_max, tz_min, tz_max, t_near, t_far);
+}
+
+// ------------------------------------------------------------------------------ prims
+struct TriV {
+    V3 v0, v1, v2;
+};
+DEV TriV load_tri(const DTri *tris, int idx, int *prim_id, int *material) {
+    // 80-byte record, 16-byte aligned: five 16-byte loads
+    const double2 *p = reinterpret_cast<const double2 *>(tris + idx);
+    double2 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    TriV t;
+    t.v0 = v3(a.x, a.y, b.x);
+    t.v1 = v3(b.y, c.x, c.y);
+    t.v2 = v3(d.x, d.y, e.x);
+    long long ids = __double_as_longlong(e.y);
+    *prim_id = (int)(ids & 0xFFFFFFFFLL);
+    *material = (int)(ids >> 32);
+    return t;
+}
+// Triangle::intersects up to t, geometry/prims/triangle.rs:111-133 (Möller–Trumbore, two-sided)
+DEV bool tri_hit(const TriV &tr, const Ray &r, double t_min, double t_max, double *t_out, double *beta_out,
+                 double *gamma_out) {
+    V3 d = v3(r.dx, r.dy, r.dz), o = v3(r.ox, r.oy, r.oz);
+    V3 e1 = tr.v1 - tr.v0;
+    V3 e2 = tr.v2 - tr.v0;
+    V3 p = cross(d, e2);
+    double det = dot(e1, p);
+    if (det > -F64_EPSILON && det < F64_EPSILON) return false;
+    double inv_det = 1.0 / det;
+    V3 s = o - tr.v0;
+    double beta = inv_det * dot(s, p);
+    if (beta < 0.0 || beta > 1.0) return false;
+    V3 q = cross(s, e1);
+    double gamma = inv_det * dot(d, q);
+    if (gamma < 0.0 || beta + gamma > 1.0) return false;
+    double t = inv_det * dot(e2, q);
+    if (t < t_min || t > t_max) return false;
+    *t_out = t; *beta_out = beta; *gamma_out = gamma;
+    return true;
+}
+// The leaf entry's own bbox (octree.rs:170) = the prim's partial_bounding_box
+// (triangle.rs:102-106: union of the three vertices), recomputed instead of stored.
+DEV bool tri_bbox_hit(const TriV &tr, const Ray &r) {
+    double tn, tf;
+    return slab(fmin(fmin(tr.v0.x, tr.v1.x), tr.v2.x), fmin(fmin(tr.v0.y, tr.v1.y), tr.v2.y),
+                fmin(fmin(tr.v0.z, tr.v1.z), tr.v2.z), fmax(fmax(tr.v0.x, tr.v1.x), tr.v2.x),
+                fmax(fmax(tr.v0.y, tr.v1.y), tr.v2.y), fmax(fmax(tr.v0.z, tr.v1.z), tr.v2.z), r, &tn, &tf);
+}
+// Sphere::intersects up to the choice of t, geometry/prims/sphere.rs:36-54.  *t_out is the root
+// with the smaller |t| even when that root is outside the window (sphere.rs:54).
+DEV bool sphere_hit(V3 c, double radius, const Ray &r, double t_min, double t_max, double *t_out) {
+    V3 d = v3(r.dx, r.dy, r.dz);
+    V3 i = v3(r.ox, r.oy, r.oz) - c;
+    double a_ = 1.0;
+    double b_ = 2.0 * dot(d, i);
+    double c_ = dot(i, i) - radius * radius;
+    double discriminant = b_ * b_ - 4.0 * a_ * c_;
+    if (discriminant <= 0.0) return false;
+    double disc_sqrt = sqrt(discriminant);
+    double t1 = (-b_ + disc_sqrt) / 2.0 * a_;
+    double t2 = (-b_ - disc_sqrt) / 2.0 * a_;
+    if ((t1 >= t_min && t1 <= t_max) || (t2 >= t_min && t2 <= t_max)) {
+        *t_out = fabs(t1) < fabs(t2) ? t1 : t2;
+        return true;
+    }
+    return false;
+}
+DEV bool sphere_bbox_hit(V3 c, double radius, const Ray &r) {                            // sphere.rs:18-33
+    double tn, tf;
+    return slab(c.x - radius, c.y - radius, c.z - radius, c.x + radius, c.y + radius, c.z + radius, r, &tn, &tf);
+}
+DEV bool plane_hit(const DPlane &pl, const Ray &r, double t_min, double t_max, double *t_out) { // plane.rs:26-33
+    V3 n = v3(pl.abcd[0], pl.abcd[1], pl.abcd[2]);
+    double nrd = dot(n, v3(r.dx, r.dy, r.dz));
+    double nro = dot(n, v3(r.ox, r.oy, r.oz));
+    double t = (-pl.abcd[3] - nro) / nrd;
+    if (t < t_min || t > t_max) return false;
+    *t_out = t;
+    return true;
+}
+
+// ------------------------------------------------------------------------------ octree traversal
+// OctreeIterator (raytracer/octree.rs:135-189) restated as an iterative walk with a per-lane
+// LEVEL stack in LDS: one 32-bit word per tree level = (first_child << 8) | pending-children
+// mask.  Interior nodes always have 8 contiguous children (octree.rs:75-98), so a level needs
+// nothing more, and the stack is <= depth words instead of the reference's 1+7*depth pointers.
+//
+// MODE_CLOSEST:      near-to-far, nodes culled against the best t, terminates when the best hit
+//                    lies inside the current leaf's span (result-preserving: Appendix A).
+// MODE_CLOSEST_REF:  the reference's exact visitation order (children popped 7..0, no culling),
+//                    so exact-t ties between different prims resolve as in ray.rs:52-60.
+// MODE_ANY:          shadow feeler when every material is opaque: stop at the first occluder
+//                    inside [EPSILON, dist] (the product would be exactly 0 from there on).
+// MODE_PRODUCT:      shadow feeler with transmissive materials: every candidate of the
+//                    multiset, duplicates included (renderer.rs:209-217), order-free product.
+enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3 };
+
+struct Hit {
+    double t;
+    int ref;       // >= 0 triangle, < 0 ~sphere, INT_MIN none; planes: 0x40000000 | index
+};
+constexpr int REF_NONE = (int)0x80000000;
+constexpr int REF_PLANE = 0x40000000;
+
+template <int MODE>
+DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride RTX_BLOCK */, double t_lo, double t_hi,
+                  Hit *hit, V3 *prod) {
+    double best_t = t_hi;           // closest: nearest_t (ray.rs:47); shadows: distance_to_light
+    int best_ref = REF_NONE;
+    V3 acc = v3(1.0, 1.0, 1.0);     // shadow product (renderer.rs:211)
+    bool done = false;
+    const uint32_t flip = (MODE == MODE_CLOSEST_REF) ? 7u : r.flip;
+
+    int sp = 0;
+    int cur = 0;                    // root: never tested against the ray (octree.rs:149,177)
+    bool have_cur = true;
+    double cur_far = -inf();
+
+    while (!done) {
+        if (!have_cur) {
+            while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
+            if (sp == 0) break;
+            uint32_t e = stk[(sp - 1) * RTX_BLOCK];
+            uint32_t j = (uint32_t)__ffs((int)(e & 0xFFu)) - 1u;
+            stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
+            cur = (int)(e >> 8) + (int)(j ^ flip);
+        }
+        const DNode *np = sc.nodes + cur;
+        // 64-byte node record: four 16-byte loads
+        const double2 *nq = reinterpret_cast<const double2 *>(np);
+        double2 q0 = nq[0], q1 = nq[1], q2 = nq[2];
+        int4 meta = *reinterpret_cast<const int4 *>(nq + 3);
+        double minx = q0.x, miny = q0.y, minz = q1.x, maxx = q1.y, maxy = q2.x, maxz = q2.y;
+        int first_child = meta.x, entry_begin = meta.y, entry_count = meta.z;
+        uint32_t child_mask = (uint32_t)meta.w;
+        if (!have_cur) {
+            if (MODE == MODE_CLOSEST || MODE == MODE_ANY) {
+                // the parent already found this box hit; recompute its span to cull it
+                double tn, tf;
+                slab(minx, miny, minz, maxx, maxy, maxz, r, &tn, &tf);
+                if (tn > best_t) continue;
+                cur_far = tf;
+            }
+        }
+        have_cur = false;
+
+        if (first_child >= 0) {
+            // children's boxes exactly as OctreeNode::subdivide computes them (octree.rs:79-92):
+            // low half = [min, max - len/2], high half = [min + len/2, max]
+            double hx = (maxx - minx) / 2.0, hy = (maxy - miny) / 2.0, hz = (maxz - minz) / 2.0;
+            double mlx = maxx - hx, mhx = minx + hx;
+            double mly = maxy - hy, mhy = miny + hy;
+            double mlz = maxz - hz, mhz = minz + hz;
+            // slab distances of the 4 planes per axis, arranged as (near half tmin, tmax), (far half tmin, tmax)
+            double ax0 = ((r.sx ? minx : maxx) - r.ox) * r.ix, ax1 = ((r.sx ? mlx : mhx) - r.ox) * r.ix;
+            double ax2 = ((r.sx ? mhx : mlx) - r.ox) * r.ix, ax3 = ((r.sx ? maxx : minx) - r.ox) * r.ix;
+            double ay0 = ((r.sy ? miny : maxy) - r.oy) * r.iy, ay1 = ((r.sy ? mly : mhy) - r.oy) * r.iy;
+            double ay2 = ((r.sy ? mhy : mly) - r.oy) * r.iy, ay3 = ((r.sy ? maxy : miny) - r.oy) * r.iy;
+            double az0 = ((r.sz ? minz : maxz) - r.oz) * r.iz, az1 = ((r.sz ? mlz : mhz) - r.oz) * r.iz;
+            double az2 = ((r.sz ? mhz : mlz) - r.oz) * r.iz, az3 = ((r.sz ? maxz : minz) - r.oz) * r.iz;
+            uint32_t pending = 0;
+            if (MODE == MODE_CLOSEST_REF) {
+                // reference order: j = 7 - k; the near/far arrangement above is indexed by the ray's
+                // own flip, so translate k -> near-order bits with r.flip
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    if (!((child_mask >> k) & 1u)) continue;
+                    uint32_t b = k ^ r.flip;
+                    double tn, tf;
+                    bool ok = slab_combine((b & 4u) ? ax2 : ax0, (b & 4u) ? ax3 : ax1, (b & 2u) ? ay2 : ay0,
+                                           (b & 2u) ? ay3 : ay1, (b & 1u) ? az2 : az0, (b & 1u) ? az3 : az1, &tn, &tf);
+                    if (ok) pending |= 1u << (k ^ 7u);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    if (!((child_mask >> (j ^ flip)) & 1u)) continue;
+                    double tn, tf;
+                    bool ok = slab_combine((j & 4u) ? ax2 : ax0, (j & 4u) ? ax3 : ax1, (j & 2u) ? ay2 : ay0,
+                                           (j & 2u) ? ay3 : ay1, (j & 1u) ? az2 : az0, (j & 1u) ? az3 : az1, &tn, &tf);
+                    if (MODE == MODE_CLOSEST || MODE == MODE_ANY) ok = ok && !(tn > best_t);
+                    if (ok) pending |= 1u << j;
+                }
+            }
+            if (pending) {
+                stk[sp * RTX_BLOCK] = ((uint32_t)first_child << 8) | pending;
+                ++sp;
+            }
+        } else {
+            for (int e = entry_begin; e < entry_begin + entry_count; ++e) {
+                int ref = sc.leaf_refs[e];
+                if (ref >= 0) {
+                    int pid, mat;
+                    TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                    if (!tri_bbox_hit(tr, r)) continue;
+                    double t, be, ga;
+                    if (MODE == MODE_CLOSEST || MODE == MODE_CLOSEST_REF) {
+                        // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
+                        if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                            best_t = t;
+                            best_ref = ref;
+                        }
+                    } else if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
+                        if (MODE == MODE_ANY) { best_ref = ref; done = true; break; }
+                        const rtx_material &m = sc.materials[mat];
+                        if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                        else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                        if (acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0) { done = true; break; }
+                    }
+                } else {
+                    const DSphere &sp_ = sc.spheres[~ref];
+                    V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                    double radius = sp_.r;
+                    if (!sphere_bbox_hit(c, radius, r)) continue;
+                    double t;
+                    if (MODE == MODE_CLOSEST || MODE == MODE_CLOSEST_REF) {
+                        if (sphere_hit(c, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                            best_t = t;
+                            best_ref = ref;
+                        }
+                    } else if (sphere_hit(c, radius, r, t_lo, t_hi, &t)) {
+                        if (MODE == MODE_ANY) { best_ref = ref; done = true; break; }
+                        const rtx_material &m = sc.materials[sp_.material];
+                        if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                        else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                        if (acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0) { done = true; break; }
+                    }
+                }
+            }
+            // near-to-far: everything still pending starts behind this leaf's exit
+            if (MODE == MODE_CLOSEST && best_ref != REF_NONE && best_t <= cur_far) done = true;
+        }
+    }
+
+    // infinite prims last, in order (octree.rs:163-165,185-186)
+    if (!(MODE == MODE_ANY && done) && !(MODE == MODE_PRODUCT && done)) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            const DPlane &pl = sc.planes[p];
+            double t;
+            if (MODE == MODE_CLOSEST || MODE == MODE_CLOSEST_REF) {
+                if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                    best_t = t;
+                    best_ref = REF_PLANE | p;
+                }
+            } else if (plane_hit(pl, r, t_lo, t_hi, &t)) {
+                if (MODE == MODE_ANY) { best_ref = REF_PLANE | p; break; }
+                const rtx_material &m = sc.materials[pl.material];
+                if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+            }
+        }
+    }
+    hit->t = best_t;
+    hit->ref = best_ref;
+    if (MODE == MODE_ANY) *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+    else *prod = acc;
+}
+
+// ------------------------------------------------------------------------------ textures
+struct C4 {
+    double r, g, b, a;
+};
+DEV C4 px_f64(const uint8_t *atlas, const DImage &im, long long x, long long y) {
+    // the reference panics out of range (surface.rs:102-109; only 1-pixel-wide/high images): clamp
+    if (x >= im.w) x = im.w - 1;
+    if (y >= im.h) y = im.h - 1;
+    uchar4 p = *reinterpret_cast<const uchar4 *>(atlas + im.offset + (y * (long long)im.w + x) * 4);
+    return C4{p.x / 255.0, p.y / 255.0, p.z / 255.0, p.w / 255.0};                      // colorrgba.rs:116-124
+}
+DEV C4 cmul(C4 c, double s) { return C4{c.r * s, c.g * s, c.b * s, c.a}; }               // colorrgba.rs:178-189
+DEV C4 cadd(C4 a, C4 b) { return C4{a.r + b.r, a.g + b.g, a.b + b.b, a.a + b.a}; }       // colorrgba.rs:138-148
+DEV long long as_usize(double v) {                                                       // saturating `as usize`
+    if (!(v > 0.0)) return 0;
+    if (v >= 9.0e18) return 0x7FFFFFFFFFFFFFFFLL;
+    return (long long)v;
+}
+DEV V3 image_color(const DScene &sc, int image, double u, double v) {                    // imagetexture.rs:26-47
+    const DImage im = sc.images[image];
+    double s = fmod(u, 1.0) * ((double)im.w - 1.0);
+    double t = fmod(v, 1.0) * ((double)im.h - 1.0);
+    long long x = as_usize(floor(s));
+    long long y = as_usize(floor(t));
+    double u_ratio = s - (double)x;
+    double v_ratio = t - (double)y;
+    double u_opposite = 1.0 - u_ratio;
+    double v_opposite = 1.0 - v_ratio;
+    C4 c = cadd(cmul(cadd(cmul(px_f64(sc.atlas, im, x, y), u_opposite), cmul(px_f64(sc.atlas, im, x + 1, y), u_ratio)), v_opposite),
+                cmul(cadd(cmul(px_f64(sc.atlas, im, x, y + 1), u_opposite), cmul(px_f64(sc.atlas, im, x + 1, y + 1), u_ratio)), v_ratio));
+    return v3(c.r / 1.0, c.g / 1.0, c.b / 1.0);                                          // to_vec3, colorrgba.rs:128-135
+}
+DEV V3 texture_color(const DScene &sc, int tex, double u, double v) {
+    const rtx_texture &tx = sc.textures[tex];
+    if (tx.kind == RTX_TEX_CHECKER) {                                                    // checkertexture.rs:13-23
+        double s = fabs(fmod(u, tx.scale));
+        double t = fabs(fmod(v, tx.scale));
+        double half = tx.scale / 2.0;
+        if ((s > half && t < half) || (s < half && t > half))
+            return v3(tx.color1[0] / 1.0, tx.color1[1] / 1.0, tx.color1[2] / 1.0);
+        return v3(tx.color2[0] / 1.0, tx.color2[1] / 1.0, tx.color2[2] / 1.0);
+    }
+    if (tx.kind == RTX_TEX_UV) return v3((fmod(u, 1.0) + 0.0) / 1.0, (fmod(v, 1.0) + 0.0) / 1.0, 0.0 / 1.0); // uvtexture.rs:10-14
+    return image_color(sc, tx.image, u, v);
+}
+DEV V3 cubemap_color(const DScene &sc, V3 dir) {                                         // cubemap.rs:45-84
+    double x_mag = fabs(dir.x), y_mag = fabs(dir.y), z_mag = fabs(dir.z);
+    int face = -1;
+    double s = 0.0, t = 0.0;
+    if (x_mag >= y_mag && x_mag >= z_mag) {
+        face = dir.x <= 0.0 ? 0 : 1;
+        double sc_ = dir.x < 0.0 ? 1.0 : -1.0;
+        s = sc_ * dir.z / fabs(dir.x);
+        t = dir.y / fabs(dir.x);
+    } else if (y_mag >= x_mag && y_mag >= z_mag) {
+        face = dir.y <= 0.0 ? 2 : 3;
+        double sc_ = dir.y < 0.0 ? 1.0 : -1.0;
+        s = sc_ * dir.x / fabs(dir.y);
+        t = dir.z / fabs(dir.y);
+    } else if (z_mag >= y_mag && z_mag >= x_mag) {
+        face = dir.z <= 0.0 ? 4 : 5;
+        double sc_ = dir.z < 0.0 ? -1.0 : 1.0;
+        s = sc_ * dir.x / fabs(dir.z);
+        t = dir.y / fabs(dir.z);
+    }
+    double seam_delta = 0.0001;
+    s = fmin(fmax(1.0 - (s * 0.5 + 0.5), seam_delta), 1.0 - seam_delta);
+    t = fmin(fmax(1.0 - (t * 0.5 + 0.5), seam_delta), 1.0 - seam_delta);
+    if (face < 0) return v3(0.0, 0.0, 0.0); // NaN direction: the reference panics (cubemap.rs:79-81)
+    return image_color(sc, sc.skybox[face], s, t);
+}
+
+// ------------------------------------------------------------------------------ materials
+DEV V3 material_sample(const DScene &sc, const rtx_material &m, V3 n, V3 i, V3 l, double u, double v) {
+    V3 diffuse_c = v3(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
+    if (m.kind == RTX_MAT_FLAT) return diffuse_c;                                        // flatmaterial.rs:11-13
+    V3 ambient_c = v3(m.ambient[0], m.ambient[1], m.ambient[2]);
+    V3 specular_c = v3(m.specular[0], m.specular[1], m.specular[2]);
+    V3 texc = m.texture >= 0 ? texture_color(sc, m.texture, u, v) : v3(1.0 / 1.0, 1.0 / 1.0, 1.0 / 1.0);
+    if (m.kind == RTX_MAT_COOK_TORRANCE) {                                               // cooktorrancematerial.rs:26-58
+        V3 ambient = scale(ambient_c, m.k_a);
+        V3 diffuse = scale(scale(diffuse_c, m.k_d), dot(n, l)) * texc;
+        V3 h = unit(l + i);
+        double n_dot_h = dot(n, h);
+        double n_dot_l = dot(n, l);
+        double v_dot_h = dot(i, h);
+        double n_dot_v = dot(n, i);
+        double n1 = 1.0, n2 = m.ior;
+        double f0r = (n1 - n2) / (n1 + n2);
+        double f0 = f0r * f0r;
+        double f = pow(1.0 - v_dot_h, 5.0) * (1.0 - f0) + f0;
+        double alpha = acos(n_dot_h);
+        double d = m.gauss_constant * exp(-alpha / sqrt(m.shine));
+        double g1 = (2.0 * n_dot_h * n_dot_v) / v_dot_h;
+        double g2 = (2.0 * n_dot_h * n_dot_l) / v_dot_h;
+        double g = fmin(g1, g2);
+        double brdf = f * d * g / (n_dot_v * n_dot_l * PI);
+        return scale(specular_c, m.k_s * brdf) + diffuse + ambient;
+    }
+    V3 h = unit(l + i);                                                                  // phongmaterial.rs:24-36
+    V3 ambient = scale(ambient_c, m.k_a);
+    V3 diffuse = scale(scale(diffuse_c, m.k_d), dot(n, l)) * texc;
+    V3 specular = scale(scale(specular_c, m.k_s), pow(dot(n, h), m.shine));
+    return ambient + diffuse + specular;
+}
+DEV double fresnel_reflect(double ior, V3 i, V3 n, bool inside) {                       // renderer.rs:226-247
+    double n1 = inside ? ior : 1.0, n2 = inside ? 1.0 : ior;
+    V3 actual_n = inside ? -n : n;
+    double r0_sqrt = (n1 - n2) / (n1 + n2);
+    double r0 = r0_sqrt * r0_sqrt;
+    double cos_angle;
+    if (n1 <= n2) {
+        cos_angle = dot(i, actual_n);
+    } else {
+        V3 t;
+        if (!refract(i, -actual_n, ior, inside, &t)) return 1.0;
+        cos_angle = -dot(actual_n, t);
+    }
+    double cos_term = 1.0 - cos_angle;
+    return fmin(fmax(r0 + ((1.0 - r0) * cos_term * cos_term * cos_term * cos_term * cos_term), 0.0), 1.0);
+}
+
+// ------------------------------------------------------------------------------ queues
+DEV uint32_t lane_id() { return __lane_id(); }
+// Wave-aggregated append: one atomic per wave per queue.  Must be reached by every lane that
+// is active at the call site with the same `counter`.
+DEV uint32_t wave_append(bool want, uint32_t *counter) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0u;
+    uint32_t n = (uint32_t)__popcll(mask);
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, n);
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+}
+DEV void count_rays(bool valid, unsigned long long *counter) {
+    unsigned long long mask = __ballot(valid);
+    if (mask != 0ull && (int)lane_id() == __ffsll((long long)mask) - 1) atomicAdd(counter, (unsigned long long)__popcll(mask));
+}
+DEV void acc_add(double *acc, uint32_t sample, V3 c) {
+    double *p = acc + (size_t)sample * 3;
+    unsafeAtomicAdd(p + 0, c.x);   // global_atomic_add_f64 on gfx950
+    unsafeAtomicAdd(p + 1, c.y);
+    unsafeAtomicAdd(p + 2, c.z);
+}
+
+// sample index -> pixel: samples are laid out so that one wave64 = one 8x8 pixel tile of one
+// sub-sample (coherent primary rays): s = ((tile * spp + sub) * 64 + lane)
+DEV bool decode_sample(const DFrame &fr, uint32_t s, uint32_t *px, uint32_t *row, uint32_t *sub) {
+    uint32_t per_tile = 64u * fr.spp;
+    uint32_t tile = s / per_tile, rem = s % per_tile;
+    *sub = rem >> 6;
+    uint32_t lane = rem & 63u;
+    uint32_t tx = tile % fr.tiles_x, j = tile / fr.tiles_x;
+    uint32_t block_row = fr.shard_index + j * fr.shard_count;
+    *px = tx * 8u + (lane & 7u);
+    *row = block_row * 8u + (lane >> 3);
+    return *px < fr.W && *row < fr.H;
+}
+
+DEV void pool_store(const DPool &pool, uint32_t slot, V3 o, V3 d, V3 thr, uint64_t key, uint32_t sample, uint32_t flags) {
+    size_t cap = pool.cap;
+    double *f = pool.f + slot;
+    f[0 * cap] = o.x; f[1 * cap] = o.y; f[2 * cap] = o.z;
+    f[3 * cap] = d.x; f[4 * cap] = d.y; f[5 * cap] = d.z;
+    f[6 * cap] = thr.x; f[7 * cap] = thr.y; f[8 * cap] = thr.z;
+    pool.key[slot] = key;
+    pool.sample[slot] = sample;
+    pool.flags[slot] = flags;
+}
+
+} // namespace
+
+// ================================================================================ kernels
+
+// K1 primary_gen: render_tile's loops (renderer.rs:72-92) + Camera::get_ray (camera.rs:62-68)
+__global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count) {
+    uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t s = s0 + gid;
+    uint32_t px, row, sub;
+    bool valid = decode_sample(fr, s, &px, &row, &sub);
+    uint32_t slot = pool_base + gid;
+    if (!valid) {
+        pool.flags[slot] = RAYF_DEAD;
+        return;
+    }
+    uint32_t abs_x = px, abs_y = fr.H - row - 1u;                                        // renderer.rs:73
+    uint32_t x_subpixel = sub % fr.ps, y_subpixel = sub / fr.ps;
+    uint64_t key = root_key(fr.seed, fr.frame, abs_y * fr.W + abs_x, sub);
+    double j_x = 0.0, j_y = 0.0;
+    if (fr.ps > 1) {                                                                     // renderer.rs:84-89
+        double ua, ub;
+        draw2(fr.rng_mode, key, STREAM_JITTER, 0, 0, &ua, &ub);
+        j_x = (double)x_subpixel * fr.inv_ps + ua * fr.inv_ps;
+        j_y = (double)y_subpixel * fr.inv_ps + ub * fr.inv_ps;
+    }
+    double x = (double)abs_x + j_x, y = (double)abs_y + j_y;
+    V3 eye = v3(fr.eye[0], fr.eye[1], fr.eye[2]), right = v3(fr.right[0], fr.right[1], fr.right[2]);
+    V3 up = v3(fr.up[0], fr.up[1], fr.up[2]);
+    V3 dir = unit(eye + scale(right, x * fr.pixel_width - fr.half_width) + scale(up, y * fr.pixel_height - fr.half_height));
+    uint32_t flags = (fr.reflect_depth << RAYF_REFLECT_SHIFT) | (fr.refract_depth << RAYF_REFRACT_SHIFT) |
+                     ((uint32_t)RAY_PRIMARY << RAYF_TYPE_SHIFT);
+    pool_store(pool, slot, v3(fr.pos[0], fr.pos[1], fr.pos[2]), dir, v3(1.0, 1.0, 1.0), key, s, flags);
+}
+
+// K2+K3 (+K5): Ray::get_nearest_hit (ray.rs:44-66), then the body of Renderer::trace
+// (renderer.rs:108-144): local shading per light -> one shadow group per (hit, light);
+// reflection / gloss / transmission children -> ray pool; miss -> skybox / background.
+template <int MODE>
+__global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
+                                                      DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out) {
+    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    bool valid = gid < count;
+    uint32_t slot = begin + (valid ? gid : 0u);
+    uint32_t flags = valid ? pool.flags[slot] : RAYF_DEAD;
+    valid = valid && !(flags & RAYF_DEAD);
+
+    size_t cap = pool.cap;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(0, 0, 0);
+    uint64_t key = 0;
+    uint32_t sample = 0;
+    if (valid) {
+        const double *f = pool.f + slot;
+        o = v3(f[0 * cap], f[1 * cap], f[2 * cap]);
+        d = v3(f[3 * cap], f[4 * cap], f[5 * cap]);
+        thr = v3(f[6 * cap], f[7 * cap], f[8 * cap]);
+        key = pool.key[slot];
+        sample = pool.sample[slot];
+    }
+    uint32_t reflect_depth = (flags >> RAYF_REFLECT_SHIFT) & RAYF_DEPTH_MASK;
+    uint32_t refract_depth = (flags >> RAYF_REFRACT_SHIFT) & RAYF_DEPTH_MASK;
+    bool inside = (flags & RAYF_INSIDE) != 0u;
+    uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
+
+    count_rays(valid && type == RAY_PRIMARY, &counters->rays[RAY_PRIMARY]);
+    count_rays(valid && type == RAY_REFLECT, &counters->rays[RAY_REFLECT]);
+    count_rays(valid && type == RAY_GLOSS, &counters->rays[RAY_GLOSS]);
+    count_rays(valid && type == RAY_REFRACT, &counters->rays[RAY_REFRACT]);
+
+    Ray r = make_ray(o, d);
+    Hit hit;
+    hit.t = inf();
+    hit.ref = REF_NONE;
+    V3 unused;
+    if (valid) traverse<MODE>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+
+    bool is_hit = valid && hit.ref != REF_NONE;
+
+    // ---- full Intersection of the winning prim (recomputed: same arithmetic, same bits)
+    V3 hn = v3(0, 0, 1), hp = v3(0, 0, 0);
+    double hu = 0.0, hv = 0.0;
+    int material = 0, prim_id = -1;
+    if (is_hit) {
+        double t = hit.t;
+        hp = o + scale(d, t);                                                            // origin + direction.scale(t)
+        if (hit.ref >= 0 && !(hit.ref & REF_PLANE)) {                                    // triangle.rs:136-145
+            TriV tr = load_tri(sc.tris, hit.ref, &prim_id, &material);
+            double tt, beta, gamma;
+            tri_hit(tr, r, -inf(), inf(), &tt, &beta, &gamma);
+            double alpha = 1.0 - beta - gamma;
+            const double2 *sp2 = reinterpret_cast<const double2 *>(sc.tri_shade + hit.ref);
+            double2 a0 = sp2[0], a1 = sp2[1], a2 = sp2[2], a3 = sp2[3], a4 = sp2[4], a5 = sp2[5], a6 = sp2[6], a7 = sp2[7];
+            V3 n0 = v3(a0.x, a0.y, a1.x), n1 = v3(a1.y, a2.x, a2.y), n2 = v3(a3.x, a3.y, a4.x);
+            double u0 = a4.y, v0 = a5.x, u1 = a5.y, v1 = a6.x, u2 = a6.y, v2 = a7.x;
+            hn = scale(n0, alpha) + scale(n1, beta) + scale(n2, gamma);
+            hu = u0 * alpha + u1 * beta + u2 * gamma;
+            hv = v0 * alpha + v1 * beta + v2 * gamma;
+        } else if (hit.ref >= 0) {                                                       // plane.rs:35-39
+            const DPlane &pl = sc.planes[hit.ref & ~REF_PLANE];
+            prim_id = pl.prim_id; material = pl.material;
+            V3 n = v3(pl.abcd[0], pl.abcd[1], pl.abcd[2]);
+            V3 u_axis = v3(n.y, n.z, -n.x);
+            V3 v_axis = cross(u_axis, n);
+            hn = n;
+            hu = dot(hp, u_axis);
+            hv = dot(hp, v_axis);
+        } else {                                                                         // sphere.rs:55-59
+            const DSphere &sp_ = sc.spheres[~hit.ref];
+            prim_id = sp_.prim_id; material = sp_.material;
+            V3 n = unit(hp - v3(sp_.c[0], sp_.c[1], sp_.c[2]));
+            hn = n;
+            hu = 0.5 + atan2(n.z, n.x) / (PI * 2.0);
+            hv = 0.5 - asin(n.y) / PI;
+        }
+    }
+
+    if (valid && type == RAY_PRIMARY && prim_id_out) {
+        uint32_t px, row, sub;
+        decode_sample(fr, sample, &px, &row, &sub);
+        if (sub == 0u) prim_id_out[(size_t)row * fr.W + px] = is_hit ? prim_id : -1;
+    }
+
+    // ---- miss: skybox / background (renderer.rs:139-144)
+    if (valid && !is_hit) {
+        V3 c = sc.has_skybox ? cubemap_color(sc, d) : v3(sc.background[0], sc.background[1], sc.background[2]);
+        acc_add(acc, sample, thr * c);
+    }
+
+    // ---- hit: local lighting (renderer.rs:110-119)
+    const rtx_material &m = sc.materials[material];
+    V3 n = v3(0, 0, 1), iv = v3(0, 0, 1);
+    if (is_hit) {
+        n = unit(hn);
+        iv = unit(-d);
+    }
+    for (int li = 0; li < sc.n_lights; ++li) {
+        V3 w = v3(0, 0, 0);
+        bool emit = false;
+        if (is_hit) {
+            const rtx_light &lt = sc.lights[li];
+            V3 l = unit(v3(lt.position[0], lt.position[1], lt.position[2]) - hp);
+            V3 smp = material_sample(sc, m, n, iv, l, hu, hv);
+            w = thr * (v3(lt.color[0], lt.color[1], lt.color[2]) * smp);
+            if (fr.shadow_samples == 0u) acc_add(acc, sample, w);                        // renderer.rs:191: shadow = one
+            else emit = true;
+        }
+        uint32_t gslot = wave_append(emit, &counters->shadow_tail[li]);
+        if (emit) {
+            if (gslot < sq.cap) {
+                size_t qc = sq.cap;
+                double *f = sq.f + (size_t)li * 6 * qc + gslot;
+                f[0 * qc] = hp.x; f[1 * qc] = hp.y; f[2 * qc] = hp.z;
+                f[3 * qc] = w.x; f[4 * qc] = w.y; f[5 * qc] = w.z;
+                sq.key[(size_t)li * qc + gslot] = key;
+                sq.sample[(size_t)li * qc + gslot] = sample;
+            } else {
+                counters->overflow = 1u;
+            }
+        }
+    }
+
+    // ---- global lighting: spawn the child trace() calls (renderer.rs:122-135, 148-186)
+    bool reflective = is_hit && m.kind != RTX_MAT_FLAT && m.k_sg > 0.0;
+    bool refractive = is_hit && m.kind != RTX_MAT_FLAT && m.k_tg > 0.0;
+    double reflect_fresnel = 0.0;
+    if (reflective || refractive) reflect_fresnel = fresnel_reflect(m.ior, iv, n, inside);
+    double refract_fresnel = 1.0 - reflect_fresnel;
+
+    // a child whose depth counter reaches 0 returns zero at renderer.rs:106 and is not a ray
+    bool spawn_reflect = reflective && reflect_depth > 1u && refract_depth > 0u;
+    bool glossy = m.kind != RTX_MAT_FLAT && m.glossiness > F64_EPSILON;
+    V3 rdir = v3(0, 0, 1);
+    if (spawn_reflect) rdir = reflect(iv, n);
+    uint32_t child_flags_reflect = ((reflect_depth - 1u) << RAYF_REFLECT_SHIFT) | (refract_depth << RAYF_REFRACT_SHIFT) |
+                                   (inside ? RAYF_INSIDE : 0u);
+    {   // mirror reflection (renderer.rs:164)
+        bool want = spawn_reflect && !glossy;
+        uint32_t cs = wave_append(want, &counters->pool_tail);
+        if (want) {
+            if (cs < pool.cap)
+                pool_store(pool, cs, hp, rdir, scale(scale(thr, m.k_sg), reflect_fresnel), child_key(key, CODE_MIRROR), sample,
+                           child_flags_reflect | ((uint32_t)RAY_REFLECT << RAYF_TYPE_SHIFT));
+            else counters->overflow = 1u;
+        }
+    }
+    if (__any(spawn_reflect && glossy)) {   // glossy reflection: gloss_samples perturbed rays, averaged (renderer.rs:155-161)
+        double inv_g = 1.0 / (double)fr.gloss_samples;
+        for (uint32_t g = 0; g < fr.gloss_samples; ++g) {
+            bool want = spawn_reflect && glossy;
+            V3 gdir = rdir;
+            uint64_t ck = 0;
+            if (want) {   // Ray::perturb (ray.rs:68-81) with Vec3::random (vec3.rs:112-126)
+                ck = child_key(key, CODE_GLOSS0 + g);
+                double u_phi, u_cos, u_r, un;
+                draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 0, &u_phi, &u_cos);
+                draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 1, &u_r, &un);
+                double phi = 0.0 + (2.0 * PI - 0.0) * u_phi;
+                double costheta = -1.0 + (1.0 - -1.0) * u_cos;
+                double uu = 0.0 + (1.0 - 0.0) * u_r;
+                double theta = acos(costheta);
+                double rr = pow(uu, 1.0 / 3.0);
+                V3 rand_vec = scale(v3(rr * sin(theta) * cos(phi), rr * sin(theta) * sin(phi), rr * cos(theta)), m.glossiness);
+                V3 corrected = dot(rand_vec, rdir) < 0.0 ? scale(rand_vec, -1.0) : rand_vec;
+                gdir = unit(corrected + rdir);
+            }
+            uint32_t cs = wave_append(want, &counters->pool_tail);
+            if (want) {
+                if (cs < pool.cap)
+                    pool_store(pool, cs, hp, gdir, scale(scale(scale(thr, inv_g), m.k_sg), reflect_fresnel), ck, sample,
+                               child_flags_reflect | ((uint32_t)RAY_GLOSS << RAYF_TYPE_SHIFT));
+                else counters->overflow = 1u;
+            }
+        }
+    }
+    {   // transmission (renderer.rs:170-186): TIR -> mirror direction with weight 1.0, `!inside` either way
+        bool want = refractive && refract_depth > 1u && reflect_depth > 0u;
+        V3 tdir = v3(0, 0, 1);
+        double actual = refract_fresnel;
+        if (want) {
+            if (!refract(iv, n, m.ior, inside, &tdir)) {
+                tdir = reflect(iv, n);
+                actual = 1.0;
+            }
+        }
+        uint32_t cs = wave_append(want, &counters->pool_tail);
+        if (want) {
+            uint32_t cf = (reflect_depth << RAYF_REFLECT_SHIFT) | ((refract_depth - 1u) << RAYF_REFRACT_SHIFT) |
+                          (inside ? 0u : RAYF_INSIDE) | ((uint32_t)RAY_REFRACT << RAYF_TYPE_SHIFT);
+            if (cs < pool.cap)
+                pool_store(pool, cs, hp + scale(tdir, EPSILON), tdir, scale(scale(thr, m.k_tg), actual),
+                           child_key(key, CODE_TRANSMIT), sample, cf);
+            else counters->overflow = 1u;
+        }
+    }
+}
+
+// K4 trace_shadow: Renderer::shadow_intensity (renderer.rs:188-221), one feeler per lane; the
+// `tries` feelers of one (hit, light) pair sit in adjacent lanes and are reduced with
+// cross-lane shuffles before ONE set of atomics per group.
+template <int MODE>
+__global__ void __launch_bounds__(RTX_BLOCK) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+                                                       uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
+    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
+    bool valid = group < n_groups;
+    size_t qc = sq.cap;
+    V3 hp = v3(0, 0, 0), w = v3(0, 0, 0);
+    uint64_t key = 0;
+    uint32_t sample = 0;
+    if (valid) {
+        const double *f = sq.f + (size_t)light * 6 * qc + group;
+        hp = v3(f[0 * qc], f[1 * qc], f[2 * qc]);
+        w = v3(f[3 * qc], f[4 * qc], f[5 * qc]);
+        key = sq.key[(size_t)light * qc + group];
+        sample = sq.sample[(size_t)light * qc + group];
+    }
+    count_rays(valid, &counters->rays[RAY_SHADOW]);
+
+    V3 v = v3(0, 0, 0);
+    if (valid) {
+        const rtx_light &lt = sc.lights[light];
+        V3 sampled = v3(lt.position[0], lt.position[1], lt.position[2]);
+        if (lt.kind != RTX_LIGHT_POINT) {                                                // spherelight.rs:13-23
+            double ux, uy, uz, un;
+            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k, &ux, &uy);
+            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k + 1u, &uz, &un);
+            V3 jitter = v3(lt.radius * (ux - 0.5), lt.radius * (uy - 0.5), lt.radius * (uz - 0.5));
+            sampled = sampled + jitter;
+        }
+        V3 shadow_l = unit(sampled - hp);                                                // renderer.rs:203
+        Ray r = make_ray(hp, shadow_l);                                                  // NO origin offset (renderer.rs:204)
+        double distance_to_light = len(sampled - hp);
+        Hit hit;
+        traverse<MODE>(sc, r, s_stk + threadIdx.x, EPSILON, distance_to_light, &hit, &v);
+    }
+    double inv_tries = 1.0 / (double)tries;
+    if (pow2_tries) {
+        // groups are lane-aligned (tries divides 64 and RTX_BLOCK): butterfly sum over the group
+        for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
+            v.x += __shfl_xor(v.x, (int)off);
+            v.y += __shfl_xor(v.y, (int)off);
+            v.z += __shfl_xor(v.z, (int)off);
+        }
+        if (valid && k == 0u) acc_add(acc, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
+    } else if (valid) {
+        acc_add(acc, sample, w * scale(v, inv_tries));
+    }
+}
+
+// K6 resolve: per-sample clamp + average (renderer.rs:95) and ColorRGBA::new_rgb_clamped
+// (compositor/colorrgba.rs:68-76); row 0 = top (Surface::merge, surface.rs:83-94)
+__global__ void __launch_bounds__(RTX_BLOCK) k_resolve(DFrame fr, const double *acc, uint8_t *rgba_out) {
+    uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    uint32_t n_pix = fr.n_blocks_local * fr.tiles_x * 64u;
+    if (gid >= n_pix) return;
+    uint32_t tile = gid >> 6, lane = gid & 63u;
+    uint32_t px, row, sub;
+    uint32_t s0 = (tile * fr.spp) * 64u + lane;
+    if (!decode_sample(fr, s0, &px, &row, &sub)) return;
+    V3 color = v3(0.0, 0.0, 0.0);
+    for (uint32_t sb = 0; sb < fr.spp; ++sb) {
+        const double *p = acc + (size_t)(s0 + sb * 64u) * 3;
+        color = color + scale(v3(clamp01(p[0]), clamp01(p[1]), clamp01(p[2])), fr.inv_spp);
+    }
+    double c[3] = {color.x, color.y, color.z};
+    uchar4 out;
+    uint8_t q[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        double rv = round(c[ch] * 255.0);      // f64::round: half away from zero
+        int iv = (rv != rv) ? 0 : (rv <= -2147483648.0 ? (int)0x80000000 : (rv >= 2147483647.0 ? 0x7FFFFFFF : (int)rv));
+        iv = iv > 255 ? 255 : (iv < 0 ? 0 : iv);
+        q[ch] = (uint8_t)iv;
+    }
+    out.x = q[0]; out.y = q[1]; out.z = q[2]; out.w = 255;
+    *reinterpret_cast<uchar4 *>(rgba_out + ((size_t)row * fr.W + px) * 4) = out;
+}
+
+// Probe kernels behind rtx_nearest_hits / rtx_shadow_products
+template <int MODE>
+__global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, const double *origin, const double *direction,
+                                                        int32_t *prim_id, double *t_out) {
+    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (gid >= n) return;
+    V3 o = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
+    V3 d = v3(direction[gid * 3], direction[gid * 3 + 1], direction[gid * 3 + 2]);
+    Ray r = make_ray(o, d);
+    Hit hit;
+    V3 unused;
+    traverse<MODE>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    int pid = -1;
+    if (hit.ref != REF_NONE) {
+        if (hit.ref >= 0 && !(hit.ref & REF_PLANE)) pid = sc.tris[hit.ref].prim_id;
+        else if (hit.ref >= 0) pid = sc.planes[hit.ref & ~REF_PLANE].prim_id;
+        else pid = sc.spheres[~hit.ref].prim_id;
+    }
+    prim_id[gid] = pid;
+    t_out[gid] = hit.ref != REF_NONE ? hit.t : inf();
+}
+template <int MODE>
+__global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_t n, const double *origin, const double *target,
+                                                                double *out) {
+    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (gid >= n) return;
+    V3 p = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
+    V3 s = v3(target[gid * 3], target[gid * 3 + 1], target[gid * 3 + 2]);
+    V3 l = unit(s - p);
+    Ray r = make_ray(p, l);
+    double dist = len(s - p);
+    Hit hit;
+    V3 v;
+    traverse<MODE>(sc, r, s_stk + threadIdx.x, EPSILON, dist, &hit, &v);
+    out[gid * 3] = v.x; out[gid * 3 + 1] = v.y; out[gid * 3 + 2] = v.z;
+}
+
+// ================================================================================ launch wrappers
+static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + RTX_BLOCK - 1) / RTX_BLOCK); }
+
+void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, fr, pool, pool_base, s0, count);
+}
+void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
+                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out) {
+    if (count == 0) return;
+    if (fr.flags & RTX_FLAG_REFERENCE_ORDER)
+        hipLaunchKernelGGL(k_trace<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool,
+                           begin, count, sq, counters, acc, prim_id_out);
+    else
+        hipLaunchKernelGGL(k_trace<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin,
+                           count, sq, counters, acc, prim_id_out);
+}
+void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+                 uint32_t tries, DCounters *counters, double *acc) {
+    if (n_groups == 0 || tries == 0) return;
+    uint32_t pow2 = (tries <= 64u && (tries & (tries - 1u)) == 0u) ? 1u : 0u;
+    uint64_t lanes = (uint64_t)n_groups * tries;
+    if (sc.all_opaque)
+        hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+    else
+        hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+}
+void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out) {
+    uint64_t n_pix = (uint64_t)fr.n_blocks_local * fr.tiles_x * 64u;
+    if (n_pix == 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_pix)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, fr, acc, rgba_out);
+}
+void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *direction,
+                  int32_t *prim_id, double *t_out, uint32_t flags) {
+    if (n <= 0) return;
+    if (flags & RTX_FLAG_REFERENCE_ORDER)
+        hipLaunchKernelGGL(k_nearest<MODE_CLOSEST_REF>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
+                           origin, direction, prim_id, t_out);
+    else
+        hipLaunchKernelGGL(k_nearest<MODE_CLOSEST>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n, origin,
+                           direction, prim_id, t_out);
+}
+void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
+                          double *out) {
+    if (n <= 0) return;
+    // always the multiset product here: with all-opaque scenes it equals the any-hit answer
+    hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
+                       origin, target, out);
+}

@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference's seam: `Renderer::render(camera, Arc<Scene>) -> Surface`
+(src/raytracer/renderer.rs:24-65) on top of the C ABI.  `Scene` owns an rtx_scene handle (the
+flattened scene resident in HBM); `Renderer` carries the RenderOptions and calls rtx_render.
+Everything here goes through librtx.so; if it is missing, `abi.load()` raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .desc import options as make_options
+
+
+class Scene:
+    """Arc<Scene> counterpart: a scene flattened, octree-indexed and uploaded to one GPU."""
+
+    def __init__(self, flat, device=0):
+        self._lib = abi.load()
+        self.flat = flat
+        h = C.c_void_p()
+        abi.check(self._lib.rtx_scene_create(C.byref(flat.desc), device, C.byref(h)), "rtx_scene_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.rtx_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        inf = abi.SceneInfo()
+        abi.check(self._lib.rtx_scene_get_info(self.h, C.byref(inf)), "rtx_scene_get_info")
+        return inf
+
+    def render(self, cam, opt, want_ids=True, out=None):
+        """rtx_render into host arrays: returns (rgba[H,W,4] u8, prim_id[H,W] i32 or None, Stats)."""
+        H, W = cam.image_height, cam.image_width
+        rgba = out if out is not None else np.zeros((H, W, 4), dtype=np.uint8)
+        ids = np.full((H, W), -2, dtype=np.int32) if want_ids else None
+        st = abi.Stats()
+        abi.check(self._lib.rtx_render(self.h, C.byref(cam), C.byref(opt), rgba.ctypes.data_as(C.c_void_p),
+                                       ids.ctypes.data_as(C.c_void_p) if want_ids else None, C.byref(st)),
+                  "rtx_render")
+        return rgba, ids, st
+
+    def render_device(self, cam, opt, rgba_ptr, ids_ptr=None, stream=None, want_stats=True):
+        """rtx_render_device: outputs are device pointers (ints), e.g. torch tensors' data_ptr()."""
+        st = abi.Stats() if want_stats else None
+        abi.check(self._lib.rtx_render_device(self.h, C.byref(cam), C.byref(opt), C.c_void_p(rgba_ptr),
+                                              C.c_void_p(ids_ptr) if ids_ptr else None,
+                                              C.c_void_p(stream) if stream else None,
+                                              C.byref(st) if want_stats else None), "rtx_render_device")
+        return st
+
+    def nearest_hits(self, origin, direction):
+        o = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        pid = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float64)
+        abi.check(self._lib.rtx_nearest_hits(self.h, n, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                             pid.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)),
+                  "rtx_nearest_hits")
+        return pid, t
+
+    def shadow_products(self, origin, target):
+        o = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)
+        s = np.ascontiguousarray(target, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros_like(o)
+        abi.check(self._lib.rtx_shadow_products(self.h, o.shape[0], o.ctypes.data_as(C.c_void_p),
+                                                s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
+                  "rtx_shadow_products")
+        return out
+
+
+def octree_dump(flat):
+    """rtx_octree_dump (no device needed): (depth, bbox[n,6], shape[n,2], entries)."""
+    lib = abi.load()
+    depth, nn, ne = C.c_int32(), C.c_int64(), C.c_int64()
+    abi.check(lib.rtx_octree_dump(C.byref(flat.desc), C.byref(depth), C.byref(nn), C.byref(ne), None, None, None),
+              "rtx_octree_dump")
+    bbox = np.zeros((nn.value, 6), dtype=np.float64)
+    shape = np.zeros((nn.value, 2), dtype=np.int32)
+    entries = np.zeros(max(1, ne.value), dtype=np.int32)
+    abi.check(lib.rtx_octree_dump(C.byref(flat.desc), None, None, None, bbox.ctypes.data_as(C.c_void_p),
+                                  shape.ctypes.data_as(C.c_void_p), entries.ctypes.data_as(C.c_void_p)),
+              "rtx_octree_dump")
+    return depth.value, bbox, shape, entries[:ne.value]
+
+
+class Renderer:
+    """renderer.rs:24-27: `tasks` is kept for API parity (the GPU path has no thread pool)."""
+
+    def __init__(self, options=None, tasks=0, **kw):
+        self.tasks = tasks
+        self.options = options if options is not None else make_options(**kw)
+
+    def render(self, camera, scene):
+        rgba, _, _ = scene.render(camera, self.options, want_ids=False)
+        return rgba

@@ -1,0 +1,223 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Bars (BASELINE.json north_star): in deterministic mode (rng_mode=center) primary-ray hit prim
+ids bit-exact on >= 99.99 % of pixels and 8-bit RGB within +-1 on >= 99.9 % of pixels.
+Closest-hit ids and t from rtx_nearest_hits must be bit-exact (integer/index work and IEEE f64
+with the reference's operation order; only libm transcendentals may differ by ulps, and those
+only feed shading)."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rtx, which):
+    if which == "sphere":
+        return scenes.sphere_scene(rtx)
+    if which == "cornell":
+        return scenes.cornell_scene(rtx)
+    if which == "mesh":
+        return scenes.mesh_scene(rtx)
+    if which == "mesh_transmissive":
+        return scenes.mesh_scene(rtx, transmissive=True, point_light=True)
+    if which == "mesh_big":
+        return scenes.mesh_scene(rtx, n_u=96, n_v=64)
+    if which == "cube":
+        return scenes.cube_obj_scene(rtx)
+    raise KeyError(which)
+
+
+def _rays(cam_fn, orc, n, seed):
+    """Random camera-like rays plus rays from random points inside the scene."""
+    rng = np.random.RandomState(seed)
+    cam = cam_fn(64, 64)
+    o, d = [], []
+    for _ in range(n // 2):
+        r = orc.camera_get_ray(cam, rng.uniform(0, 63), rng.uniform(0, 63))
+        o.append(r["origin"]); d.append(r["direction"])
+    c = np.array(list(cam.look_at))
+    ext = np.linalg.norm(np.array(list(cam.position)) - c)
+    for _ in range(n - n // 2):
+        p = c + rng.uniform(-0.5, 0.5, size=3) * ext
+        v = rng.normal(size=3)
+        o.append(p); d.append(v / np.linalg.norm(v))
+    return np.array(o), np.array(d)
+
+
+@pytest.mark.parametrize("which", ["sphere", "cornell", "mesh", "mesh_big", "cube"])
+def test_nearest_hits_bit_exact(rtx, orc, which):
+    flat, cam_fn = _scene(rtx, which)
+    o, d = _rays(cam_fn, orc, 4096, seed=11)
+    opid, ot = orc.Scene(flat).nearest_hits(o, d)
+    sc = rtx.Scene(flat)
+    pid, t = sc.nearest_hits(o, d)
+    sc.close()
+    assert (opid >= 0).sum() > 100, "test rays should hit something"
+    assert np.array_equal(pid, opid)
+    assert np.array_equal(t.view(np.uint64), ot.view(np.uint64))
+
+
+@pytest.mark.parametrize("which", ["cornell", "mesh", "mesh_transmissive", "cube"])
+def test_shadow_products_match(rtx, orc, which):
+    flat, cam_fn = _scene(rtx, which)
+    o, d = _rays(cam_fn, orc, 2048, seed=5)
+    osc = orc.Scene(flat)
+    pid, t, hit = osc.nearest_hits(o, d, want_hit=True)
+    keep = pid >= 0
+    origins = hit[keep, 6:9]                      # shadow feelers start ON surfaces, un-offset (renderer.rs:204)
+    light = np.array(list(flat.lights[0].position))
+    targets = np.broadcast_to(light, origins.shape).copy()
+    want = osc.shadow_products(origins, targets)
+    sc = rtx.Scene(flat)
+    got = sc.shadow_products(origins, targets)
+    sc.close()
+    assert origins.shape[0] > 100
+    # products of identical factors in a different order: equal up to the last ulp
+    assert np.allclose(got, want, rtol=1e-15, atol=0.0)
+    assert np.array_equal(got == 0.0, want == 0.0)
+
+
+def _compare(rgba, ids, orgba, oids, id_bar=0.9999, rgb_bar=0.999):
+    id_ok = (ids == oids).mean()
+    diff = np.abs(rgba[..., :3].astype(np.int32) - orgba[..., :3].astype(np.int32)).max(axis=-1)
+    rgb_ok = (diff <= 1).mean()
+    assert id_ok >= id_bar, "prim-id parity %.6f" % id_ok
+    assert rgb_ok >= rgb_bar, "rgb +-1 parity %.6f (max diff %d)" % (rgb_ok, diff.max())
+    assert (rgba[..., 3] == 255).all()
+    return id_ok, rgb_ok
+
+
+DET = dict(reflect_depth=4, refract_depth=4, shadow_samples=1, gloss_samples=1, pixel_samples=1, rng_mode=0)
+
+
+@pytest.mark.parametrize("which,size", [("sphere", (64, 64)), ("cornell", (128, 128)), ("mesh", (128, 96)),
+                                        ("mesh_transmissive", (96, 64)), ("cube", (64, 64)), ("mesh_big", (160, 120))])
+def test_deterministic_render_parity(rtx, orc, which, size):
+    flat, cam_fn = _scene(rtx, which)
+    cam = cam_fn(*size)
+    opt = rtx.options(**DET)
+    orgba, oids, ocn = orc.Scene(flat).render(cam, opt)
+    sc = rtx.Scene(flat)
+    rgba, ids, st = sc.render(cam, opt)
+    sc.close()
+    _compare(rgba, ids, orgba, oids)
+    # ray accounting is identical on both sides: 1 per get_nearest_hit, 1 per shadow try
+    assert st.rays_primary == ocn.rays[0] == size[0] * size[1]
+    for got, want in ((st.rays_reflect, ocn.rays[1]), (st.rays_gloss, ocn.rays[2]), (st.rays_refract, ocn.rays[3]),
+                      (st.rays_shadow, ocn.rays[4])):
+        assert abs(int(got) - int(want)) <= max(2, 1e-3 * want), (got, want)
+
+
+def test_deep_refraction_recursion(rtx, orc):
+    """cornell's refractive sphere (ior 3, k_sg = k_tg = 1) with depth 8/8: a branching ray tree."""
+    flat, cam_fn = scenes.cornell_scene(rtx)
+    cam = cam_fn(96, 96)
+    opt = rtx.options(reflect_depth=8, refract_depth=8, shadow_samples=1, gloss_samples=1, pixel_samples=1, rng_mode=0)
+    orgba, oids, ocn = orc.Scene(flat).render(cam, opt)
+    sc = rtx.Scene(flat)
+    rgba, ids, st = sc.render(cam, opt)
+    # a small batch forces many wavefront steps and exercises the segment stack of the ray pool
+    opt2 = rtx.options(reflect_depth=8, refract_depth=8, shadow_samples=1, gloss_samples=1, pixel_samples=1, rng_mode=0,
+                       batch_rays=1024)
+    rgba2, ids2, st2 = sc.render(cam, opt2)
+    sc.close()
+    _compare(rgba, ids, orgba, oids)
+    _compare(rgba2, ids2, orgba, oids)
+    assert st.rays_refract > 0 and abs(int(st.rays_refract) - int(ocn.rays[3])) <= 1e-3 * ocn.rays[3] + 2
+    assert st2.rays_total == st.rays_total
+
+
+def test_stochastic_render_same_rng(rtx, orc):
+    """Philox mode: oracle and kernels implement the same counter-based RNG spec independently,
+    so supersampled, soft-shadowed, glossy images agree to the same +-1 bar."""
+    flat, cam_fn = scenes.cornell_scene(rtx, glossy=True)
+    cam = cam_fn(64, 64)
+    opt = rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=4, gloss_samples=2, pixel_samples=2, rng_mode=1, seed=7)
+    orgba, oids, ocn = orc.Scene(flat).render(cam, opt)
+    sc = rtx.Scene(flat)
+    rgba, ids, st = sc.render(cam, opt)
+    sc.close()
+    _compare(rgba, ids, orgba, oids, rgb_bar=0.995)
+    assert st.rays_gloss > 0 and st.rays_primary == 64 * 64 * 4
+    a, b = rgba[..., :3].astype(np.float64) / 255.0, orgba[..., :3].astype(np.float64) / 255.0
+    assert np.sqrt(((a - b) ** 2).mean()) < 0.005     # RMSE < 0.5 %
+
+
+def test_stochastic_converges_to_high_spp_reference(rtx, orc):
+    """north_star: converged-image RMSE against a high-spp reference render below 0.5 %."""
+    flat, cam_fn = scenes.mesh_scene(rtx, n_u=16, n_v=12)
+    cam = cam_fn(48, 32)
+    ref_opt = rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=16, pixel_samples=4, rng_mode=1, seed=1)
+    ref = orc.Scene(flat).render_linear(cam, ref_opt)
+    sc = rtx.Scene(flat)
+    opt = rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=16, pixel_samples=4, rng_mode=1, seed=99)
+    rgba, _, _ = sc.render(cam, opt, want_ids=False)
+    sc.close()
+    got = rgba[..., :3].astype(np.float64) / 255.0
+    # different seeds: only the distribution matches; compare means (noise-free up to 1/sqrt(16*16) of the soft edges)
+    assert abs(got.mean() - np.clip(ref, 0, 1).mean()) < 0.005
+
+
+def test_empty_scene_background(rtx):
+    """raytracer/renderer.rs:251-291 it_renders_the_background_of_an_empty_scene, on the GPU."""
+    b = rtx.SceneBuilder()
+    b.background = (1.0, 0.0, 0.0)
+    sc = rtx.Scene(b.build())
+    cam = rtx.camera((0, 0, 0), (0, 1, 0), (0, 0, 1), 45.0, 32, 32)
+    rgba, ids, st = sc.render(cam, rtx.options(1, 1, 1, 1, 1))
+    sc.close()
+    assert (rgba[..., 0] == 255).all() and (rgba[..., 1] == 0).all() and (rgba[..., 2] == 0).all()
+    assert (ids == -1).all() and st.rays_primary == 1024 and st.rays_shadow == 0
+
+
+def test_zero_depth_is_black(rtx):
+    """renderer.rs:106: reflect_depth or refract_depth of 0 returns zero before any ray."""
+    flat, cam_fn = scenes.sphere_scene(rtx)
+    sc = rtx.Scene(flat)
+    rgba, _, st = sc.render(cam_fn(32, 32), rtx.options(reflect_depth=0, refract_depth=4), want_ids=False)
+    sc.close()
+    assert (rgba[..., :3] == 0).all() and st.rays_total == 0
+
+
+def test_shards_tile_the_frame(rtx):
+    """8-row blocks dealt round-robin; shards are disjoint and partition-invariant."""
+    flat, cam_fn = scenes.mesh_scene(rtx)
+    cam = cam_fn(96, 64)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=3, refract_depth=3, shadow_samples=2, pixel_samples=2, rng_mode=1, seed=3)
+    full, ids_full, st = sc.render(cam, rtx.options(**kw))
+    out = np.zeros_like(full)
+    rays = 0
+    for k in range(3):
+        _, _, stk = sc.render(cam, rtx.options(shard_index=k, shard_count=3, **kw), want_ids=False, out=out)
+        rays += stk.rays_total
+    sc.close()
+    assert np.array_equal(out, full)
+    assert rays == st.rays_total
+
+
+def test_reference_order_flag_agrees(rtx, orc):
+    """RTX_FLAG_REFERENCE_ORDER walks the octree exactly as the reference's unordered DFS does;
+    both orders give the same image (ties between different prims are vanishingly rare)."""
+    flat, cam_fn = scenes.mesh_scene(rtx)
+    cam = cam_fn(64, 48)
+    sc = rtx.Scene(flat)
+    a, ia, _ = sc.render(cam, rtx.options(**DET))
+    b, ib, _ = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_REFERENCE_ORDER, **DET))
+    sc.close()
+    orgba, oids, _ = orc.Scene(flat).render(cam, rtx.options(**DET))
+    assert np.array_equal(ib, oids)
+    assert (ia == ib).mean() >= 0.9999
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).mean() >= 0.999
+
+
+def test_bad_arguments(rtx):
+    flat, cam_fn = scenes.sphere_scene(rtx)
+    sc = rtx.Scene(flat)
+    with pytest.raises(rtx.abi.RtxError):
+        sc.render(cam_fn(32, 30), rtx.options())            # height not a multiple of 8
+    with pytest.raises(rtx.abi.RtxError):
+        sc.render(cam_fn(32, 32), rtx.options(shard_index=2, shard_count=2))
+    sc.close()

@@ -132,11 +132,15 @@ struct Rng {
 // ---------------------------------------------------------------- counters
 struct Counters {
     uint64_t rays[5] = {0, 0, 0, 0, 0}; // primary, reflect, gloss, refract, shadow
-    uint64_t b_node = 0, b_leaf = 0, p_tri = 0, p_sph = 0, p_pln = 0;
+    // traversal work split by ray class: [0] closest-hit rays (ray.rs:44-66), [1] shadow feelers
+    uint64_t b_node[2] = {0, 0}, b_leaf[2] = {0, 0}, p_tri[2] = {0, 0}, p_sph[2] = {0, 0}, p_pln[2] = {0, 0};
     uint64_t hits = 0, mat_fetch = 0, texels = 0;
+    int cls = 0;
     void add(const Counters &o) {
         for (int i = 0; i < 5; ++i) rays[i] += o.rays[i];
-        b_node += o.b_node; b_leaf += o.b_leaf; p_tri += o.p_tri; p_sph += o.p_sph; p_pln += o.p_pln;
+        for (int c = 0; c < 2; ++c) {
+            b_node[c] += o.b_node[c]; b_leaf[c] += o.b_leaf[c]; p_tri[c] += o.p_tri[c]; p_sph[c] += o.p_sph[c]; p_pln[c] += o.p_pln[c];
+        }
         hits += o.hits; mat_fetch += o.mat_fetch; texels += o.texels;
     }
 };
@@ -390,7 +394,7 @@ struct Prim {
     bool intersects(const Ray &ray, double t_min, double t_max, Intersection *out, Counters *cn) const {
         switch (kind) {
         case RTX_PRIM_SPHERE: {                                    // sphere.rs:36-73
-            if (cn) cn->p_sph += 1;
+            if (cn) cn->p_sph[cn->cls] += 1;
             Vec3 i = ray.origin - center;
             double a_ = 1.0;
             double b_ = 2.0 * dot(ray.direction, i);
@@ -412,7 +416,7 @@ struct Prim {
             return false;
         }
         case RTX_PRIM_PLANE: {                                     // plane.rs:26-50
-            if (cn) cn->p_pln += 1;
+            if (cn) cn->p_pln[cn->cls] += 1;
             Vec3 n = v3(a, b, c);
             double nrd = dot(n, ray.direction);
             double nro = dot(n, ray.origin);
@@ -427,7 +431,7 @@ struct Prim {
             return true;
         }
         default: {                                                 // triangle.rs:111-156
-            if (cn) cn->p_tri += 1;
+            if (cn) cn->p_tri[cn->cls] += 1;
             Vec3 e1 = vertices[1] - vertices[0];
             Vec3 e2 = vertices[2] - vertices[0];
             Vec3 p = cross(ray.direction, e2);
@@ -547,11 +551,11 @@ inline void for_each_candidate(const Octree &oct, const Ray &ray, Counters *cn, 
         const OctreeNode *node = stack.back();
         stack.pop_back();
         for (const auto &child : node->children) {
-            if (cn) cn->b_node += 1;
+            if (cn) cn->b_node[cn->cls] += 1;
             if (bbox_intersects(child.bbox, ray)) stack.push_back(&child);
         }
         for (const auto &e : node->leaf_data) {
-            if (cn) cn->b_leaf += 1;
+            if (cn) cn->b_leaf[cn->cls] += 1;
             if (bbox_intersects(e.bbox, ray)) f(oct.prims[e.index]);
         }
     }
@@ -694,12 +698,14 @@ Vec3 shadow_intensity(Ctx &cx, const Intersection &hit, const Light &light, uint
         Ray shadow_ray = ray_new(hit.position, shadow_l);
         double distance_to_light = len(sampled - hit.position);
         cx.cn.rays[RAY_SHADOW] += 1;
+        cx.cn.cls = 1;
         Vec3 acc = v3(1, 1, 1);
         for_each_candidate(cx.scene->octree, shadow_ray, &cx.cn, [&](const Prim *prim) {
             Intersection occ;
             if (prim->intersects(shadow_ray, EPSILON, distance_to_light, &occ, &cx.cn))
                 acc = acc * occ.material->transmission();
         });
+        cx.cn.cls = 0;
         shadow = shadow + acc;
     }
     return scale(shadow, 1.0 / (double)tries);
@@ -825,7 +831,7 @@ extern "C" {
 
 struct orc_counters {
     uint64_t rays[5];
-    uint64_t b_node, b_leaf, p_tri, p_sph, p_pln, hits, mat_fetch, texels;
+    uint64_t b_node[2], b_leaf[2], p_tri[2], p_sph[2], p_pln[2], hits, mat_fetch, texels;
     double seconds;
     uint32_t threads;
     uint32_t pad;
@@ -1020,8 +1026,10 @@ int orc_render(const orc_scene *h, const rtx_camera *cam, const rtx_options *opt
         Counters total;
         for (auto &c : per_thread) total.add(c);
         std::memcpy(counters->rays, total.rays, sizeof(total.rays));
-        counters->b_node = total.b_node; counters->b_leaf = total.b_leaf;
-        counters->p_tri = total.p_tri; counters->p_sph = total.p_sph; counters->p_pln = total.p_pln;
+        for (int c = 0; c < 2; ++c) {
+            counters->b_node[c] = total.b_node[c]; counters->b_leaf[c] = total.b_leaf[c];
+            counters->p_tri[c] = total.p_tri[c]; counters->p_sph[c] = total.p_sph[c]; counters->p_pln[c] = total.p_pln[c];
+        }
         counters->hits = total.hits; counters->mat_fetch = total.mat_fetch; counters->texels = total.texels;
         counters->seconds = std::chrono::duration<double>(t1 - t0).count();
         counters->threads = threads;

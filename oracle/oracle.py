@@ -17,9 +17,11 @@ abi = importlib.import_module("rust-raytracer_amd.abi")
 
 
 class Counters(C.Structure):
+    """Ray counts and reference-order traversal work; the [2] arrays split the work by ray class:
+    [0] closest-hit rays (primary/reflect/gloss/refract), [1] shadow feelers."""
     _fields_ = [
-        ("rays", C.c_uint64 * 5), ("b_node", C.c_uint64), ("b_leaf", C.c_uint64),
-        ("p_tri", C.c_uint64), ("p_sph", C.c_uint64), ("p_pln", C.c_uint64),
+        ("rays", C.c_uint64 * 5), ("b_node", C.c_uint64 * 2), ("b_leaf", C.c_uint64 * 2),
+        ("p_tri", C.c_uint64 * 2), ("p_sph", C.c_uint64 * 2), ("p_pln", C.c_uint64 * 2),
         ("hits", C.c_uint64), ("mat_fetch", C.c_uint64), ("texels", C.c_uint64),
         ("seconds", C.c_double), ("threads", C.c_uint32), ("pad", C.c_uint32),
     ]
@@ -28,21 +30,51 @@ class Counters(C.Structure):
     def rays_total(self):
         return sum(self.rays)
 
-    def algorithmic_bytes(self):
-        """bytes the reference-order traversal touches, f64 layouts."""
-        return (48 * self.b_node + 56 * self.b_leaf + 72 * self.p_tri + 32 * self.p_sph +
-                32 * self.p_pln + (72 + 48 + 4) * self.hits + 168 * self.mat_fetch + 4 * self.texels)
+    @property
+    def rays_closest(self):
+        return sum(self.rays[:4])
 
-    def algorithmic_flops(self):
-        return (12 * (self.b_node + self.b_leaf) + 55 * self.p_tri + 25 * self.p_sph +
-                12 * self.p_pln + 120 * self.mat_fetch)
+    def traversal_bytes(self, cls):
+        """SURVEY.md §8d, traversal part: 48 B per child-bbox test, 56 B per leaf entry (bbox +
+        index), 72 B per triangle test, 32 B per sphere / plane test (f64 layouts of the reference)."""
+        return (48 * self.b_node[cls] + 56 * self.b_leaf[cls] + 72 * self.p_tri[cls] +
+                32 * self.p_sph[cls] + 32 * self.p_pln[cls])
+
+    def algorithmic_bytes(self, cls=None):
+        """bytes the reference-order algorithm touches.  cls 0 adds the per-hit
+        shading fetches (normals+uv+material id, material rows, texels) to the closest-hit class."""
+        shade = (72 + 48 + 4) * self.hits + 168 * self.mat_fetch + 4 * self.texels
+        if cls is None:
+            return self.traversal_bytes(0) + self.traversal_bytes(1) + shade
+        return self.traversal_bytes(cls) + (shade if cls == 0 else 0)
+
+    def algorithmic_flops(self, cls=None):
+        f = lambda c: (12 * (self.b_node[c] + self.b_leaf[c]) + 55 * self.p_tri[c] + 25 * self.p_sph[c] + 12 * self.p_pln[c])
+        shade = 120 * self.mat_fetch
+        if cls is None:
+            return f(0) + f(1) + shade
+        return f(cls) + (shade if cls == 0 else 0)
+
+    def add(self, o):
+        for i in range(5):
+            self.rays[i] += o.rays[i]
+        for name in ("b_node", "b_leaf", "p_tri", "p_sph", "p_pln"):
+            a, b = getattr(self, name), getattr(o, name)
+            a[0] += b[0]
+            a[1] += b[1]
+        self.hits += o.hits
+        self.mat_fetch += o.mat_fetch
+        self.texels += o.texels
+        self.seconds += o.seconds
+        self.threads = o.threads
 
     def as_dict(self):
-        return {"rays_primary": self.rays[0], "rays_reflect": self.rays[1], "rays_gloss": self.rays[2],
-                "rays_refract": self.rays[3], "rays_shadow": self.rays[4], "b_node": self.b_node,
-                "b_leaf": self.b_leaf, "p_tri": self.p_tri, "p_sph": self.p_sph, "p_pln": self.p_pln,
-                "hits": self.hits, "mat_fetch": self.mat_fetch, "texels": self.texels,
-                "seconds": self.seconds, "threads": self.threads}
+        d = {"rays_primary": self.rays[0], "rays_reflect": self.rays[1], "rays_gloss": self.rays[2],
+             "rays_refract": self.rays[3], "rays_shadow": self.rays[4], "hits": self.hits,
+             "mat_fetch": self.mat_fetch, "texels": self.texels, "seconds": self.seconds, "threads": self.threads}
+        for name in ("b_node", "b_leaf", "p_tri", "p_sph", "p_pln"):
+            d[name] = list(getattr(self, name))
+        return d
 
 
 def build(force=False):

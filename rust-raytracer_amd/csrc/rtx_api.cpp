@@ -369,12 +369,27 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     if (n_samples64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "more than 2^32 samples in one call");
     uint32_t n_samples = (uint32_t)n_samples64;
 
-    uint32_t batch = opt->batch_rays ? opt->batch_rays : (4u << 20);
+    // Ray pool sizing.  The pool is a stack of segments processed depth-first (deepest generation
+    // first, at most `batch` rays per launch), so generation g holds at most batch*fanout rays and
+    // the live total is bounded by batch * (1 + fanout * levels), levels = longest child chain.
+    uint32_t fanout = 0, levels = 0;
+    if (s->any_reflective) {
+        fanout += s->any_glossy ? std::max<uint32_t>(1, opt->gloss_samples) : 1;
+        levels += opt->reflect_depth > 1 ? opt->reflect_depth - 1 : 0;
+    }
+    if (s->any_refractive) {
+        fanout += 1;
+        levels += opt->refract_depth > 1 ? opt->refract_depth - 1 : 0;
+    }
+    if (levels == 0) fanout = 0;
+    uint64_t need_per_batch = 1 + (uint64_t)fanout * levels;
+    uint32_t batch = opt->batch_rays;
+    if (!batch) {   // default: 4 Mi rays per launch, shrunk so that the pool stays <= 64 Mi rays (5.6 GB)
+        uint64_t b = (64ull << 20) / need_per_batch;
+        batch = (uint32_t)std::min<uint64_t>(4u << 20, std::max<uint64_t>(b, 256u << 10));
+    }
     batch = std::max<uint32_t>(batch, RTX_BLOCK);
-    uint32_t fanout = 0;
-    if (s->any_reflective) fanout += s->any_glossy ? std::max<uint32_t>(1, opt->gloss_samples) : 1;
-    if (s->any_refractive) fanout += 1;
-    uint64_t pool_cap64 = opt->pool_rays ? opt->pool_rays : (uint64_t)batch * (fanout > 1 ? 16 : 2);
+    uint64_t pool_cap64 = opt->pool_rays ? opt->pool_rays : (uint64_t)batch * need_per_batch;
     pool_cap64 = std::max<uint64_t>(pool_cap64, (uint64_t)batch * (1 + fanout));
     if (pool_cap64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "ray pool above 2^32 rays");
     uint32_t pool_cap = (uint32_t)pool_cap64;
@@ -453,23 +468,21 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if (children) segs.push_back(Seg{top_end, top_end + children});
         peak_pool = std::max<uint64_t>(peak_pool, (uint64_t)top_end + children);
 
-        Span sp_s{nullptr, nullptr, 1};
-        bool any_shadow = false;
         for (size_t li = 0; li < s->lights.size(); ++li) {
             uint32_t groups = w.h_back->shadow_tail[li];
             if (!groups) continue;
             uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194
-            if (timing && !any_shadow) {
+            Span sp_s{nullptr, nullptr, 1};
+            if (timing) {   // one event pair per launch, so ms_shadow / launches_shadow is a kernel duration
                 if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
                 HIPCHECK(hipEventRecord(sp_s.a, stream));
             }
-            any_shadow = true;
             rtxk_shadow(stream, s->d, fr, w.sq, (uint32_t)li, groups, tries, w.d_counters, w.acc);
             ++launches_shadow;
-        }
-        if (timing && any_shadow) {
-            HIPCHECK(hipEventRecord(sp_s.b, stream));
-            spans.push_back(sp_s);
+            if (timing) {
+                HIPCHECK(hipEventRecord(sp_s.b, stream));
+                spans.push_back(sp_s);
+            }
         }
     }
     rtxk_resolve(stream, fr, w.acc, d_rgba);

@@ -167,6 +167,12 @@ def main():
                                 "shadow": ms_shadow, "launches_closest": l_closest, "launches_shadow": l_shadow},
         }
 
+        wk = [[int(r0.work[c][k]) for k in range(3)] for c in range(2)]
+        if any(any(w) for w in wk):   # RTX_LIB=librtx_count.so: what the kernels actually walked, per ray
+            out["gpu_work_per_ray"] = {
+                "closest": dict(zip(("nodes", "leaf_entries", "prim_tests"), [w / max(1, closest_rays) for w in wk[0]])),
+                "shadow": dict(zip(("nodes", "leaf_entries", "prim_tests"), [w / max(1, r0.rays_shadow) for w in wk[1]]))}
+
         cpu = None
         if args.cpu_blocks > 0:
             orc = importlib.import_module("oracle.oracle")   # the checker + CPU baseline, never the product

@@ -196,7 +196,11 @@ typedef struct rtx_stats {
     uint32_t launches_closest;
     uint32_t launches_shadow;
     uint64_t peak_pool_rays;
-    uint64_t reserved[4];
+    /* traversal work actually done by the kernels, all 0 unless the library was built with
+     * -DRTX_COUNT_WORK (librtx_count.so, profiling only): [0] closest-hit rays, [1] shadow
+     * feelers; nodes visited, leaf entries fetched, primitive tests run */
+    uint64_t work[2][3];
+    uint64_t reserved[2];
 } rtx_stats;
 
 typedef struct rtx_scene_info {

@@ -97,7 +97,7 @@ class Stats(C.Structure):
         ("ms_total", C.c_double), ("ms_device", C.c_double),
         ("ms_closest", C.c_double), ("ms_shadow", C.c_double),
         ("launches_closest", C.c_uint32), ("launches_shadow", C.c_uint32),
-        ("peak_pool_rays", C.c_uint64), ("reserved", C.c_uint64 * 4),
+        ("peak_pool_rays", C.c_uint64), ("work", (C.c_uint64 * 3) * 2), ("reserved", C.c_uint64 * 2),
     ]
 
     @property
@@ -123,7 +123,8 @@ EXPORTS = (
 )
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx.so")
+# RTX_LIB=librtx_count.so selects the profiling twin (same ABI, kernels also count their work)
+LIB_PATH = os.path.join(_HERE, os.environ.get("RTX_LIB", "librtx.so"))
 _lib = None
 
 

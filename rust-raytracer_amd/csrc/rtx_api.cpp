@@ -499,6 +499,8 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         stats->rays_gloss = w.h_back->rays[RAY_GLOSS];
         stats->rays_refract = w.h_back->rays[RAY_REFRACT];
         stats->rays_shadow = w.h_back->rays[RAY_SHADOW];
+        for (int c = 0; c < 2; ++c)
+            for (int k = 0; k < 3; ++k) stats->work[c][k] = w.h_back->work[c][k];
         float ms = 0.f;
         HIPCHECK(hipEventElapsedTime(&ms, ev_first, ev_last));
         stats->ms_device = ms;
@@ -601,6 +603,49 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         for (int e : hn.entries) leaf_refs.push_back(ref_of_prim[(size_t)e]);
         max_entries = std::max(max_entries, (int)hn.entries.size());
     }
+    // conservative f32 twins (DNode32 / DEntry32): relative to the root centre, rounded outward
+    auto f32_down = [](double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; };
+    auto f32_up = [](double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; };
+    double centre[3], radius = 0.0;
+    for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (oct.nodes[0].bbox.mn[a] + oct.nodes[0].bbox.mx[a]);
+    auto widen_radius = [&](const HBox &b) {
+        for (int a = 0; a < 3; ++a) {
+            double lo = std::fabs(b.mn[a] - centre[a]), hi = std::fabs(b.mx[a] - centre[a]);
+            if (lo > radius) radius = lo;
+            if (hi > radius) radius = hi;
+        }
+    };
+    std::vector<DNode32> nodes32(oct.nodes.size());
+    std::vector<DEntry32> entries32;
+    entries32.reserve(leaf_refs.size());
+    for (size_t i = 0; i < oct.nodes.size(); ++i) {
+        const HNode &hn = oct.nodes[i];
+        DNode32 &dn = nodes32[i];
+        widen_radius(hn.bbox);
+        for (int a = 0; a < 3; ++a) {
+            dn.bmin[a] = f32_down(hn.bbox.mn[a] - centre[a]);
+            dn.bmax[a] = f32_up(hn.bbox.mx[a] - centre[a]);
+        }
+        if (hn.first_child >= 0) {
+            dn.link = ((uint32_t)hn.first_child << 8) | nodes[i].child_mask;
+            dn.aux = 0xFFFFFFFFu;
+        } else {
+            dn.link = (uint32_t)entries32.size();
+            dn.aux = (uint32_t)hn.entries.size();
+        }
+        for (int e : hn.entries) {
+            const HBox &pb = oct.prim_box[(size_t)e];
+            widen_radius(pb);
+            DEntry32 de;
+            for (int a = 0; a < 3; ++a) {
+                de.bmin[a] = f32_down(pb.mn[a] - centre[a]);
+                de.bmax[a] = f32_up(pb.mx[a] - centre[a]);
+            }
+            de.ref = ref_of_prim[(size_t)e];
+            de.pad = 0;
+            entries32.push_back(de);
+        }
+    }
     // images -> one RGBA8 atlas
     std::vector<DImage> images((size_t)d->n_images);
     std::vector<uint8_t> atlas;
@@ -625,7 +670,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     }
 
     DScene &ds = s->d;
-    if ((st = upload(s.get(), nodes, &ds.nodes)) || (st = upload(s.get(), leaf_refs, &ds.leaf_refs)) ||
+    if ((st = upload(s.get(), nodes32, &ds.nodes32)) || (st = upload(s.get(), entries32, &ds.entries32)) ||
+        (st = upload(s.get(), nodes, &ds.nodes)) || (st = upload(s.get(), leaf_refs, &ds.leaf_refs)) ||
         (st = upload(s.get(), tris, &ds.tris)) || (st = upload(s.get(), shade, &ds.tri_shade)) ||
         (st = upload(s.get(), spheres, &ds.spheres)) || (st = upload(s.get(), planes, &ds.planes)) ||
         (st = upload(s.get(), materials, &ds.materials)) || (st = upload(s.get(), textures, &ds.textures)) ||
@@ -638,6 +684,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     ds.all_opaque = all_opaque ? 1 : 0;
     for (int f = 0; f < 6; ++f) ds.skybox[f] = d->skybox_image[f];
     for (int a = 0; a < 3; ++a) ds.background[a] = d->background[a];
+    for (int a = 0; a < 3; ++a) ds.centre[a] = centre[a];
+    ds.radius = radius;
 
     rtx_scene_info &info = s->info;
     info.n_finite = n_fin;

@@ -22,6 +22,24 @@ struct alignas(64) DNode {
     uint32_t child_mask;   // bit k (k = x*4+y*2+z, octree.rs:76-78): child k's subtree holds >= 1 entry
 };
 
+// Conservative single-precision twins used by the fast traversal (closest-hit with near-to-far
+// culling and any-hit shadows): boxes are relative to the root centre and rounded OUTWARD to
+// f32; the kernel widens them by a per-ray delta that covers every f32 rounding error, so the
+// f32 test never rejects a box the reference's f64 test (bbox.rs:99-165) accepts.  Survivors
+// still go through the exact f64 entry-bbox and primitive tests, so results do not change.
+struct alignas(32) DNode32 {
+    float bmin[3];
+    float bmax[3];
+    uint32_t link;   // interior: (first_child << 8) | child_mask;  leaf: entry_begin
+    uint32_t aux;    // interior: 0xFFFFFFFF;                        leaf: entry_count
+};
+struct alignas(32) DEntry32 {
+    float bmin[3];
+    float bmax[3];
+    int32_t ref;     // >= 0: triangle index, < 0: ~sphere index
+    int32_t pad;
+};
+
 // Intersection record of a triangle: 3 vertices (triangle.rs:90) + ids, 80 B, 16-B aligned.
 struct alignas(16) DTri {
     double v[9];
@@ -54,6 +72,8 @@ struct DImage {
 
 struct DScene {
     const DNode *nodes;
+    const DNode32 *nodes32;
+    const DEntry32 *entries32;  // same order as leaf_refs
     const int32_t *leaf_refs;   // >= 0: triangle index, < 0: ~sphere index
     const DTri *tris;
     const DTriShade *tri_shade;
@@ -70,6 +90,8 @@ struct DScene {
     int32_t all_opaque;
     int32_t skybox[6];
     double background[3];
+    double centre[3];           // root bbox centre: origin of the f32 coordinates
+    double radius;              // largest |coordinate - centre| of any box
 };
 
 // Camera (camera.rs:26-50,88-105) + RenderOptions (renderer.rs:14-21) + sharding, by value.
@@ -116,6 +138,9 @@ struct DCounters {
     uint32_t overflow;
     uint32_t shadow_tail[RTX_MAX_LIGHTS];
     unsigned long long rays[5];
+    // builds with -DRTX_COUNT_WORK only (librtx_count.so): [0] closest-hit rays, [1] shadow feelers;
+    // nodes visited, leaf entries fetched, prim tests run
+    unsigned long long work[2][3];
 };
 
 // ---- launch wrappers implemented in rtx_kernels.hip (all enqueue on `stream`) -----------

@@ -240,19 +240,28 @@ enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3 };
 struct Hit {
     double t;
     int ref;       // >= 0 triangle, < 0 ~sphere, INT_MIN none; planes: 0x40000000 | index
+#ifdef RTX_COUNT_WORK
+    uint32_t w_nodes, w_entries, w_prims;   // nodes visited, leaf entries fetched, prim tests run
+#endif
 };
+#ifdef RTX_COUNT_WORK
+#define WORK(x) x
+#else
+#define WORK(x)
+#endif
 constexpr int REF_NONE = (int)0x80000000;
 constexpr int REF_PLANE = 0x40000000;
 
 template <int MODE>
-DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride RTX_BLOCK */, double t_lo, double t_hi,
-                  Hit *hit, V3 *prod) {
+DEV void traverse_exact(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride RTX_BLOCK */, double t_lo, double t_hi,
+                        Hit *hit, V3 *prod) {
     double best_t = t_hi;           // closest: nearest_t (ray.rs:47); shadows: distance_to_light
     int best_ref = REF_NONE;
     V3 acc = v3(1.0, 1.0, 1.0);     // shadow product (renderer.rs:211)
     bool done = false;
     const uint32_t flip = (MODE == MODE_CLOSEST_REF) ? 7u : r.flip;
 
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
     int sp = 0;
     int cur = 0;                    // root: never tested against the ray (octree.rs:149,177)
     bool have_cur = true;
@@ -285,6 +294,7 @@ DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride R
             }
         }
         have_cur = false;
+        WORK(++w_nodes;)
 
         if (first_child >= 0) {
             // children's boxes exactly as OctreeNode::subdivide computes them (octree.rs:79-92):
@@ -331,10 +341,12 @@ DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride R
         } else {
             for (int e = entry_begin; e < entry_begin + entry_count; ++e) {
                 int ref = sc.leaf_refs[e];
+                WORK(++w_entries;)
                 if (ref >= 0) {
                     int pid, mat;
                     TriV tr = load_tri(sc.tris, ref, &pid, &mat);
                     if (!tri_bbox_hit(tr, r)) continue;
+                    WORK(++w_prims;)
                     double t, be, ga;
                     if (MODE == MODE_CLOSEST || MODE == MODE_CLOSEST_REF) {
                         // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
@@ -354,6 +366,7 @@ DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride R
                     V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
                     double radius = sp_.r;
                     if (!sphere_bbox_hit(c, radius, r)) continue;
+                    WORK(++w_prims;)
                     double t;
                     if (MODE == MODE_CLOSEST || MODE == MODE_CLOSEST_REF) {
                         if (sphere_hit(c, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
@@ -394,8 +407,182 @@ DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride R
     }
     hit->t = best_t;
     hit->ref = best_ref;
+    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
     if (MODE == MODE_ANY) *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
     else *prod = acc;
+}
+
+// Fast traversal for MODE_CLOSEST and MODE_ANY.  Node and leaf-entry boxes are tested in f32
+// against the outward-rounded DNode32 / DEntry32 twins, widened by a per-ray delta that bounds
+// every rounding error of the f32 arithmetic (origin and inverse direction rounded to f32, one
+// subtraction and one multiplication per plane: < 2^-22 * S in position units, S = largest
+// coordinate magnitude involved; delta = 2^-20 * S).  The f32 test is therefore a SUPERSET of the
+// reference's f64 BBox::intersects: it can only let extra candidates through, and every
+// candidate still passes the exact f64 entry-bbox test (octree.rs:170) and the exact primitive
+// test before it counts.  NaNs (0 * inf on axis-parallel rays) drop out of v_max3/v_min3, which
+// only weakens the cull.  Near-to-far order by direction sign is exact for octree siblings.
+DEV float f32_above(double v) {   // a float >= v (v finite or +inf)
+    float f = (float)v;
+    return f + fabsf(f) * 1.1920929e-7f;
+}
+template <int MODE>
+DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride RTX_BLOCK */, double t_lo, double t_hi,
+                       Hit *hit, V3 *prod) {
+    double best_t = t_hi;
+    int best_ref = REF_NONE;
+    bool done = false;
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
+
+    // the ray in f32, relative to the root centre; on*/of* are the origin pushed delta towards /
+    // away from the box, to be paired with the near / far plane of each slab
+    double orx = r.ox - sc.centre[0], ory = r.oy - sc.centre[1], orz = r.oz - sc.centre[2];
+    double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+    double delta = big * (1.0 / 1048576.0);
+    const bool sx = r.sx, sy = r.sy, sz = r.sz;
+    const float onx = (float)(sx ? orx + delta : orx - delta), ofx = (float)(sx ? orx - delta : orx + delta);
+    const float ony = (float)(sy ? ory + delta : ory - delta), ofy = (float)(sy ? ory - delta : ory + delta);
+    const float onz = (float)(sz ? orz + delta : orz - delta), ofz = (float)(sz ? orz - delta : orz + delta);
+    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    const uint32_t flip = r.flip;
+    float bf = f32_above(best_t);   // upper bound of best_t for the f32 culls
+
+    int sp = 0;
+    uint32_t cur = 0;
+    bool have_cur = true;           // root: never culled (octree.rs:149,177)
+    while (!done) {
+        if (!have_cur) {
+            while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
+            if (sp == 0) break;
+            uint32_t e = stk[(sp - 1) * RTX_BLOCK];
+            uint32_t j = (uint32_t)__ffs((int)(e & 0xFFu)) - 1u;
+            stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
+            cur = (e >> 8) + (j ^ flip);
+        }
+        const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
+        float4 qa = nq[0], qb = nq[1];
+        const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
+        const uint32_t link = __float_as_uint(qb.z), aux = __float_as_uint(qb.w);
+        WORK(++w_nodes;)
+        // near / far plane per axis
+        const float pnx = sx ? minx : maxx, pfx = sx ? maxx : minx;
+        const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
+        const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
+        const float t0x = (pnx - onx) * ix, t3x = (pfx - ofx) * ix;
+        const float t0y = (pny - ony) * iy, t3y = (pfy - ofy) * iy;
+        const float t0z = (pnz - onz) * iz, t3z = (pfz - ofz) * iz;
+        if (!have_cur) {
+            // the parent found this box hit; cull it if it now starts behind the best hit
+            float lo = fmaxf(fmaxf(t0x, t0y), t0z);
+            if (lo > bf) continue;
+        }
+        have_cur = false;
+
+        if (aux == 0xFFFFFFFFu) {
+            // child boxes = halves of this box (octree.rs:79-92); the f64 mid planes max - len/2 and
+            // min + len/2 differ from 0.5*(min+max) by rounding only, far inside delta
+            const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
+            const float t1x = (mx - ofx) * ix, t2x = (mx - onx) * ix;   // mid plane as far plane of the near half / near plane of the far half
+            const float t1y = (my - ofy) * iy, t2y = (my - ony) * iy;
+            const float t1z = (mz - ofz) * iz, t2z = (mz - onz) * iz;
+            // child mask in near-to-far order: bit j <- bit (j ^ flip)
+            uint32_t m = link & 0xFFu;
+            if (flip & 1u) m = ((m & 0x55u) << 1) | ((m & 0xAAu) >> 1);
+            if (flip & 2u) m = ((m & 0x33u) << 2) | ((m & 0xCCu) >> 2);
+            if (flip & 4u) m = ((m & 0x0Fu) << 4) | ((m & 0xF0u) >> 4);
+            uint32_t pending = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                float lo = fmaxf(fmaxf((j & 4u) ? t2x : t0x, (j & 2u) ? t2y : t0y), (j & 1u) ? t2z : t0z);
+                float hi = fminf(fminf((j & 4u) ? t3x : t1x, (j & 2u) ? t3y : t1y), (j & 1u) ? t3z : t1z);
+                bool ok = lo <= hi && hi >= 0.0f && !(lo > bf);
+                pending |= ok ? (1u << j) : 0u;
+            }
+            pending &= m;
+            if (pending) {
+                stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
+                ++sp;
+            }
+        } else {
+            const DEntry32 *ep = sc.entries32 + link;
+            for (uint32_t e = 0; e < aux; ++e) {
+                const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
+                float4 ea = eq[0], eb = eq[1];
+                WORK(++w_entries;)
+                {   // conservative f32 version of the entry's own bbox test (octree.rs:170)
+                    float lo = fmaxf(fmaxf(((sx ? ea.x : ea.w) - onx) * ix, ((sy ? ea.y : eb.x) - ony) * iy), ((sz ? ea.z : eb.y) - onz) * iz);
+                    float hi = fminf(fminf(((sx ? ea.w : ea.x) - ofx) * ix, ((sy ? eb.x : ea.y) - ofy) * iy), ((sz ? eb.y : ea.z) - ofz) * iz);
+                    if (!(lo <= hi && hi >= 0.0f) || lo > bf) continue;
+                }
+                int ref = __float_as_int(eb.z);
+                if (ref >= 0) {
+                    int pid, mat;
+                    TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                    if (!tri_bbox_hit(tr, r)) continue;
+                    WORK(++w_prims;)
+                    double t, be, ga;
+                    if (MODE == MODE_CLOSEST) {
+                        // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
+                        if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                            best_t = t;
+                            best_ref = ref;
+                            bf = f32_above(best_t);
+                        }
+                    } else if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
+                        best_ref = ref; done = true; break;
+                    }
+                } else {
+                    const DSphere &sp_ = sc.spheres[~ref];
+                    V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                    double radius = sp_.r;
+                    if (!sphere_bbox_hit(c, radius, r)) continue;
+                    WORK(++w_prims;)
+                    double t;
+                    if (MODE == MODE_CLOSEST) {
+                        if (sphere_hit(c, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                            best_t = t;
+                            best_ref = ref;
+                            bf = f32_above(best_t);
+                        }
+                    } else if (sphere_hit(c, radius, r, t_lo, t_hi, &t)) {
+                        best_ref = ref; done = true; break;
+                    }
+                }
+            }
+            // near-to-far: everything still pending starts behind this leaf's exit.  The exit is
+            // taken with the origin pushed delta the OTHER way, i.e. a lower bound of the true exit.
+            if (MODE == MODE_CLOSEST && best_ref != REF_NONE) {
+                float exit_lo = fminf(fminf((pfx - onx) * ix, (pfy - ony) * iy), (pfz - onz) * iz);
+                if (best_t <= (double)exit_lo) done = true;
+            }
+        }
+    }
+
+    // infinite prims last, in order (octree.rs:163-165,185-186)
+    if (!(MODE == MODE_ANY && done)) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            const DPlane &pl = sc.planes[p];
+            double t;
+            if (MODE == MODE_CLOSEST) {
+                if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                    best_t = t;
+                    best_ref = REF_PLANE | p;
+                }
+            } else if (plane_hit(pl, r, t_lo, t_hi, &t)) {
+                best_ref = REF_PLANE | p;
+                break;
+            }
+        }
+    }
+    hit->t = best_t;
+    hit->ref = best_ref;
+    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
+    if (MODE == MODE_ANY) *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+}
+
+template <int MODE>
+DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk, double t_lo, double t_hi, Hit *hit, V3 *prod) {
+    if (MODE == MODE_CLOSEST || MODE == MODE_ANY) traverse_fast<MODE>(sc, r, stk, t_lo, t_hi, hit, prod);
+    else traverse_exact<MODE>(sc, r, stk, t_lo, t_hi, hit, prod);
 }
 
 // ------------------------------------------------------------------------------ textures
@@ -538,6 +725,14 @@ DEV void count_rays(bool valid, unsigned long long *counter) {
     unsigned long long mask = __ballot(valid);
     if (mask != 0ull && (int)lane_id() == __ffsll((long long)mask) - 1) atomicAdd(counter, (unsigned long long)__popcll(mask));
 }
+#ifdef RTX_COUNT_WORK
+DEV void count_work(bool valid, const Hit &h, unsigned long long *w) {
+    if (!valid) return;
+    atomicAdd(w + 0, (unsigned long long)h.w_nodes);
+    atomicAdd(w + 1, (unsigned long long)h.w_entries);
+    atomicAdd(w + 2, (unsigned long long)h.w_prims);
+}
+#endif
 DEV void acc_add(double *acc, uint32_t sample, V3 c) {
     double *p = acc + (size_t)sample * 3;
     unsafeAtomicAdd(p + 0, c.x);   // global_atomic_add_f64 on gfx950
@@ -645,7 +840,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
     hit.t = inf();
     hit.ref = REF_NONE;
     V3 unused;
+    WORK(hit.w_nodes = hit.w_entries = hit.w_prims = 0;)
     if (valid) traverse<MODE>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    WORK(count_work(valid, hit, counters->work[0]);)
 
     bool is_hit = valid && hit.ref != REF_NONE;
 
@@ -846,6 +1043,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow(DScene sc, DFrame fr, DSha
         double distance_to_light = len(sampled - hp);
         Hit hit;
         traverse<MODE>(sc, r, s_stk + threadIdx.x, EPSILON, distance_to_light, &hit, &v);
+        WORK(count_work(true, hit, counters->work[1]);)
     }
     double inv_tries = 1.0 / (double)tries;
     if (pow2_tries) {

@@ -425,26 +425,47 @@ DEV float f32_above(double v) {   // a float >= v (v finite or +inf)
     float f = (float)v;
     return f + fabsf(f) * 1.1920929e-7f;
 }
+// LDS layout of the traversal kernels: the per-lane level stacks, then a 2 KB table that maps a
+// node's child mask into near-to-far order for each of the 8 direction-sign patterns:
+// perm[flip][mask] bit j = mask bit (j ^ flip).
+#define RTX_STK_WORDS (RTX_MAX_LEVELS * RTX_BLOCK)
+#define RTX_LDS_WORDS (RTX_STK_WORDS + 512)
+DEV void init_lds(uint32_t *s_lds) {
+    uint8_t *perm = reinterpret_cast<uint8_t *>(s_lds + RTX_STK_WORDS);
+    for (uint32_t i = threadIdx.x; i < 2048u; i += RTX_BLOCK) {
+        uint32_t flip = i >> 8, m = i & 0xFFu, o = 0;
+        for (uint32_t j = 0; j < 8u; ++j) o |= ((m >> (j ^ flip)) & 1u) << j;
+        perm[i] = (uint8_t)o;
+    }
+    __syncthreads();
+}
 template <int MODE>
-DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride RTX_BLOCK */, double t_lo, double t_hi,
-                       Hit *hit, V3 *prod) {
+DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
+    uint32_t *stk = s_lds + threadIdx.x;   // level stack, stride RTX_BLOCK
+    const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
     double best_t = t_hi;
     int best_ref = REF_NONE;
     bool done = false;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
 
-    // the ray in f32, relative to the root centre; on*/of* are the origin pushed delta towards /
-    // away from the box, to be paired with the near / far plane of each slab
-    double orx = r.ox - sc.centre[0], ory = r.oy - sc.centre[1], orz = r.oz - sc.centre[2];
-    double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
-    double delta = big * (1.0 / 1048576.0);
+    // The ray in f32 relative to the root centre: slab distance of plane p = fma(p, i, c) with
+    // c = -o*i.  The widening by delta is folded into c: cn (near planes, delta towards the
+    // origin side) and cf (far planes, delta away), h = delta * |i|.
+    const double orx = r.ox - sc.centre[0], ory = r.oy - sc.centre[1], orz = r.oz - sc.centre[2];
+    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+    const double delta = big * (1.0 / 1048576.0);
     const bool sx = r.sx, sy = r.sy, sz = r.sz;
-    const float onx = (float)(sx ? orx + delta : orx - delta), ofx = (float)(sx ? orx - delta : orx + delta);
-    const float ony = (float)(sy ? ory + delta : ory - delta), ofy = (float)(sy ? ory - delta : ory + delta);
-    const float onz = (float)(sz ? orz + delta : orz - delta), ofz = (float)(sz ? orz - delta : orz + delta);
     const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
+    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
+    // axis-parallel rays put NaNs (0 * inf) into the slab distances; max3/min3 drop them, which
+    // only weakens a cull, but the "surely inside" shortcut below must not be taken then
+    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     const uint32_t flip = r.flip;
+    const uint8_t *perm_row = perm + (flip << 8);
     float bf = f32_above(best_t);   // upper bound of best_t for the f32 culls
+    int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
 
     int sp = 0;
     uint32_t cur = 0;
@@ -459,21 +480,17 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, str
             cur = (e >> 8) + (j ^ flip);
         }
         const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
-        float4 qa = nq[0], qb = nq[1];
+        const float4 qa = nq[0], qb = nq[1];
         const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
         const uint32_t link = __float_as_uint(qb.z), aux = __float_as_uint(qb.w);
         WORK(++w_nodes;)
-        // near / far plane per axis
         const float pnx = sx ? minx : maxx, pfx = sx ? maxx : minx;
         const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
         const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
-        const float t0x = (pnx - onx) * ix, t3x = (pfx - ofx) * ix;
-        const float t0y = (pny - ony) * iy, t3y = (pfy - ofy) * iy;
-        const float t0z = (pnz - onz) * iz, t3z = (pfz - ofz) * iz;
+        const float t0x = fmaf(pnx, ix, cnx), t0y = fmaf(pny, iy, cny), t0z = fmaf(pnz, iz, cnz);
         if (!have_cur) {
             // the parent found this box hit; cull it if it now starts behind the best hit
-            float lo = fmaxf(fmaxf(t0x, t0y), t0z);
-            if (lo > bf) continue;
+            if (fmaxf(fmaxf(t0x, t0y), t0z) > bf) continue;
         }
         have_cur = false;
 
@@ -481,23 +498,19 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, str
             // child boxes = halves of this box (octree.rs:79-92); the f64 mid planes max - len/2 and
             // min + len/2 differ from 0.5*(min+max) by rounding only, far inside delta
             const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
-            const float t1x = (mx - ofx) * ix, t2x = (mx - onx) * ix;   // mid plane as far plane of the near half / near plane of the far half
-            const float t1y = (my - ofy) * iy, t2y = (my - ony) * iy;
-            const float t1z = (mz - ofz) * iz, t2z = (mz - onz) * iz;
-            // child mask in near-to-far order: bit j <- bit (j ^ flip)
-            uint32_t m = link & 0xFFu;
-            if (flip & 1u) m = ((m & 0x55u) << 1) | ((m & 0xAAu) >> 1);
-            if (flip & 2u) m = ((m & 0x33u) << 2) | ((m & 0xCCu) >> 2);
-            if (flip & 4u) m = ((m & 0x0Fu) << 4) | ((m & 0xF0u) >> 4);
+            // x carries the clamps: entry >= 0 and exit <= bf, so one compare decides a child
+            const float n0x = fmaxf(t0x, 0.0f), n1x = fmaxf(fmaf(mx, ix, cnx), 0.0f);   // near half / far half entry
+            const float f0x = fminf(fmaf(mx, ix, cfx), bf), f1x = fminf(fmaf(pfx, ix, cfx), bf);
+            const float n0y = t0y, n1y = fmaf(my, iy, cny), f0y = fmaf(my, iy, cfy), f1y = fmaf(pfy, iy, cfy);
+            const float n0z = t0z, n1z = fmaf(mz, iz, cnz), f0z = fmaf(mz, iz, cfz), f1z = fmaf(pfz, iz, cfz);
             uint32_t pending = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) {
-                float lo = fmaxf(fmaxf((j & 4u) ? t2x : t0x, (j & 2u) ? t2y : t0y), (j & 1u) ? t2z : t0z);
-                float hi = fminf(fminf((j & 4u) ? t3x : t1x, (j & 2u) ? t3y : t1y), (j & 1u) ? t3z : t1z);
-                bool ok = lo <= hi && hi >= 0.0f && !(lo > bf);
-                pending |= ok ? (1u << j) : 0u;
+                float lo = fmaxf(fmaxf((j & 4u) ? n1x : n0x, (j & 2u) ? n1y : n0y), (j & 1u) ? n1z : n0z);
+                float hi = fminf(fminf((j & 4u) ? f1x : f0x, (j & 2u) ? f1y : f0y), (j & 1u) ? f1z : f0z);
+                pending |= (lo <= hi) ? (1u << j) : 0u;
             }
-            pending &= m;
+            pending &= (uint32_t)perm_row[link & 0xFFu];
             if (pending) {
                 stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
                 ++sp;
@@ -506,18 +519,33 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, str
             const DEntry32 *ep = sc.entries32 + link;
             for (uint32_t e = 0; e < aux; ++e) {
                 const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
-                float4 ea = eq[0], eb = eq[1];
+                const float4 ea = eq[0], eb = eq[1];
                 WORK(++w_entries;)
-                {   // conservative f32 version of the entry's own bbox test (octree.rs:170)
-                    float lo = fmaxf(fmaxf(((sx ? ea.x : ea.w) - onx) * ix, ((sy ? ea.y : eb.x) - ony) * iy), ((sz ? ea.z : eb.y) - onz) * iz);
-                    float hi = fminf(fminf(((sx ? ea.w : ea.x) - ofx) * ix, ((sy ? eb.x : ea.y) - ofy) * iy), ((sz ? eb.y : ea.z) - ofz) * iz);
-                    if (!(lo <= hi && hi >= 0.0f) || lo > bf) continue;
+                // conservative f32 version of the entry's own bbox test (octree.rs:170)
+                const float enx = sx ? ea.x : ea.w, efx = sx ? ea.w : ea.x;
+                const float eny = sy ? ea.y : eb.x, efy = sy ? eb.x : ea.y;
+                const float enz = sz ? ea.z : eb.y, efz = sz ? eb.y : ea.z;
+                {
+                    float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
+                    float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), bf), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
+                    if (!(lo <= hi)) continue;
                 }
-                int ref = __float_as_int(eb.z);
+                const int ref = __float_as_int(eb.z);
+                if (ref == last_ref0 || ref == last_ref1) continue;   // already tested with a window at least as wide
+                last_ref1 = last_ref0;
+                last_ref0 = ref;
+                // the box shrunk by delta instead of widened: a ray through it passes the exact f64
+                // entry test with a margin far above f64 rounding, so that test can be skipped
+                bool surely_in = false;
+                if (finite_dir) {
+                    float lo = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
+                    float hi = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
+                    surely_in = lo <= hi && hi > 0.0f;
+                }
                 if (ref >= 0) {
                     int pid, mat;
                     TriV tr = load_tri(sc.tris, ref, &pid, &mat);
-                    if (!tri_bbox_hit(tr, r)) continue;
+                    if (!surely_in && !tri_bbox_hit(tr, r)) continue;
                     WORK(++w_prims;)
                     double t, be, ga;
                     if (MODE == MODE_CLOSEST) {
@@ -534,7 +562,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, str
                     const DSphere &sp_ = sc.spheres[~ref];
                     V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
                     double radius = sp_.r;
-                    if (!sphere_bbox_hit(c, radius, r)) continue;
+                    if (!surely_in && !sphere_bbox_hit(c, radius, r)) continue;
                     WORK(++w_prims;)
                     double t;
                     if (MODE == MODE_CLOSEST) {
@@ -549,10 +577,10 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, str
                 }
             }
             // near-to-far: everything still pending starts behind this leaf's exit.  The exit is
-            // taken with the origin pushed delta the OTHER way, i.e. a lower bound of the true exit.
+            // taken with delta the OTHER way (cn on a far plane), i.e. a lower bound of the true exit.
             if (MODE == MODE_CLOSEST && best_ref != REF_NONE) {
-                float exit_lo = fminf(fminf((pfx - onx) * ix, (pfy - ony) * iy), (pfz - onz) * iz);
-                if (best_t <= (double)exit_lo) done = true;
+                float exit_lo = fminf(fminf(fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny)), fmaf(pfz, iz, cnz));
+                if (finite_dir && best_t <= (double)exit_lo) done = true;
             }
         }
     }
@@ -580,9 +608,9 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, str
 }
 
 template <int MODE>
-DEV void traverse(const DScene &sc, const Ray &r, uint32_t *stk, double t_lo, double t_hi, Hit *hit, V3 *prod) {
-    if (MODE == MODE_CLOSEST || MODE == MODE_ANY) traverse_fast<MODE>(sc, r, stk, t_lo, t_hi, hit, prod);
-    else traverse_exact<MODE>(sc, r, stk, t_lo, t_hi, hit, prod);
+DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
+    if (MODE == MODE_CLOSEST || MODE == MODE_ANY) traverse_fast<MODE>(sc, r, s_lds, t_lo, t_hi, hit, prod);
+    else traverse_exact<MODE>(sc, r, s_lds + threadIdx.x, t_lo, t_hi, hit, prod);
 }
 
 // ------------------------------------------------------------------------------ textures
@@ -806,7 +834,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                       DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out) {
-    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    init_lds(s_stk);
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
     uint32_t slot = begin + (valid ? gid : 0u);
@@ -841,7 +870,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
     hit.ref = REF_NONE;
     V3 unused;
     WORK(hit.w_nodes = hit.w_entries = hit.w_prims = 0;)
-    if (valid) traverse<MODE>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    if (valid) traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     WORK(count_work(valid, hit, counters->work[0]);)
 
     bool is_hit = valid && hit.ref != REF_NONE;
@@ -1010,7 +1039,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
-    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
     bool valid = group < n_groups;
@@ -1042,7 +1072,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow(DScene sc, DFrame fr, DSha
         Ray r = make_ray(hp, shadow_l);                                                  // NO origin offset (renderer.rs:204)
         double distance_to_light = len(sampled - hp);
         Hit hit;
-        traverse<MODE>(sc, r, s_stk + threadIdx.x, EPSILON, distance_to_light, &hit, &v);
+        traverse<MODE>(sc, r, s_stk, EPSILON, distance_to_light, &hit, &v);
         WORK(count_work(true, hit, counters->work[1]);)
     }
     double inv_tries = 1.0 / (double)tries;
@@ -1092,7 +1122,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_resolve(DFrame fr, const double *
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, const double *origin, const double *direction,
                                                         int32_t *prim_id, double *t_out) {
-    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (gid >= n) return;
     V3 o = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
@@ -1100,7 +1131,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
     Ray r = make_ray(o, d);
     Hit hit;
     V3 unused;
-    traverse<MODE>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     int pid = -1;
     if (hit.ref != REF_NONE) {
         if (hit.ref >= 0 && !(hit.ref & REF_PLANE)) pid = sc.tris[hit.ref].prim_id;
@@ -1113,7 +1144,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_t n, const double *origin, const double *target,
                                                                 double *out) {
-    __shared__ uint32_t s_stk[RTX_MAX_LEVELS * RTX_BLOCK];
+    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (gid >= n) return;
     V3 p = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
@@ -1123,7 +1155,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_
     double dist = len(s - p);
     Hit hit;
     V3 v;
-    traverse<MODE>(sc, r, s_stk + threadIdx.x, EPSILON, dist, &hit, &v);
+    traverse<MODE>(sc, r, s_stk, EPSILON, dist, &hit, &v);
     out[gid * 3] = v.x; out[gid * 3 + 1] = v.y; out[gid * 3 + 2] = v.z;
 }
 

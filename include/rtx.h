@@ -178,6 +178,8 @@ typedef struct rtx_options {
 } rtx_options;
 
 enum {
+    RTX_FLAG_NO_COOP = 2,        /* shadow feelers walk the octree one ray per lane instead of the
+                                    cooperative 16-lane box-list traversal (A/B measurements) */
     RTX_FLAG_REFERENCE_ORDER = 1 /* closest-hit ties resolve exactly as the reference's unordered
                                     DFS would (first visited wins, ray.rs:52-60): disables
                                     near-to-far culling. Slow; for parity experiments. */
@@ -214,6 +216,8 @@ typedef struct rtx_scene_info {
     int32_t all_opaque;       /* 1 if every material's transmission() is exactly (0,0,0) */
     int64_t device_bytes;     /* bytes uploaded for the scene */
     double root_min[3], root_max[3];
+    int32_t wide_nodes;       /* 16-wide box lists of the cooperative shadow traversal (0: not used) */
+    int32_t wide_depth;
 } rtx_scene_info;
 
 typedef struct rtx_scene rtx_scene;

@@ -20,6 +20,7 @@ LIGHT_POINT, LIGHT_SPHERE = 0, 1
 PRIM_SPHERE, PRIM_PLANE, PRIM_TRIANGLE = 0, 1, 2
 RNG_CENTER, RNG_PHILOX = 0, 1
 FLAG_REFERENCE_ORDER = 1
+FLAG_NO_COOP = 2
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -112,6 +113,7 @@ class SceneInfo(C.Structure):
         ("n_nodes", C.c_int32), ("n_interior", C.c_int32), ("n_leaf_entries", C.c_int64),
         ("max_leaf_entries", C.c_int32), ("all_opaque", C.c_int32), ("device_bytes", C.c_int64),
         ("root_min", C.c_double * 3), ("root_max", C.c_double * 3),
+        ("wide_nodes", C.c_int32), ("wide_depth", C.c_int32),
     ]
 
 

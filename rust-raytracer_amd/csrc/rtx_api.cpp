@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "rtx_bvh.h"
 #include "rtx_device.h"
 
 namespace {
@@ -646,6 +647,19 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
             entries32.push_back(de);
         }
     }
+    // 16-wide box lists for the cooperative any-hit traversal
+    std::vector<RtxPrimBox> pboxes((size_t)n_fin);
+    for (int i = 0; i < n_fin; ++i) {
+        const HBox &pb = oct.prim_box[(size_t)i];
+        for (int a = 0; a < 3; ++a) { pboxes[(size_t)i].mn[a] = pb.mn[a]; pboxes[(size_t)i].mx[a] = pb.mx[a]; }
+        int32_t r = ref_of_prim[(size_t)i];
+        pboxes[(size_t)i].ref = r >= 0 ? (RTX_WREF_TRI | (uint32_t)r) : (RTX_WREF_SPHERE | (uint32_t)(~r));
+    }
+    std::vector<DBoxList> wide;
+    RtxWideStats wstats;
+    rtx_build_wide_bvh(pboxes, centre, wide, &wstats);
+    // the group stack of k_shadow_coop holds at most 15 pushes per level
+    const bool wide_ok = wstats.depth * (RTX_WIDE - 1) + 1 <= 128 && wide.size() < (1u << 26);
     // images -> one RGBA8 atlas
     std::vector<DImage> images((size_t)d->n_images);
     std::vector<uint8_t> atlas;
@@ -671,13 +685,14 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
 
     DScene &ds = s->d;
     if ((st = upload(s.get(), nodes32, &ds.nodes32)) || (st = upload(s.get(), entries32, &ds.entries32)) ||
-        (st = upload(s.get(), nodes, &ds.nodes)) || (st = upload(s.get(), leaf_refs, &ds.leaf_refs)) ||
+        (st = upload(s.get(), wide, &ds.wide)) || (st = upload(s.get(), nodes, &ds.nodes)) || (st = upload(s.get(), leaf_refs, &ds.leaf_refs)) ||
         (st = upload(s.get(), tris, &ds.tris)) || (st = upload(s.get(), shade, &ds.tri_shade)) ||
         (st = upload(s.get(), spheres, &ds.spheres)) || (st = upload(s.get(), planes, &ds.planes)) ||
         (st = upload(s.get(), materials, &ds.materials)) || (st = upload(s.get(), textures, &ds.textures)) ||
         (st = upload(s.get(), images, &ds.images)) || (st = upload(s.get(), atlas, &ds.atlas)) ||
         (st = upload(s.get(), s->lights, &ds.lights)))
         return cleanup(st);
+    if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane octree walk
     ds.n_planes = (int32_t)planes.size();
     ds.n_lights = d->n_lights;
     ds.has_skybox = d->skybox_image[0] >= 0 ? 1 : 0;
@@ -696,6 +711,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     info.n_leaf_entries = (int64_t)leaf_refs.size();
     info.max_leaf_entries = max_entries;
     info.all_opaque = ds.all_opaque;
+    info.wide_nodes = ds.wide ? (int32_t)wide.size() : 0;
+    info.wide_depth = wstats.depth;
     for (int a = 0; a < 3; ++a) { info.root_min[a] = nodes[0].bmin[a]; info.root_max[a] = nodes[0].bmax[a]; }
     *out = s.release();
     return RTX_OK;

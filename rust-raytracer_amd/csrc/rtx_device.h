@@ -40,6 +40,22 @@ struct alignas(32) DEntry32 {
     int32_t pad;
 };
 
+// A node of the 16-wide box-list hierarchy walked cooperatively by 16 lanes (one child per lane):
+// SoA so that the 16 lanes of a group read 64 contiguous bytes per array.  Boxes are relative to
+// DScene.centre and rounded outward to f32 like DNode32's.
+#define RTX_WIDE 16
+#define RTX_WREF_NODE   0x00000000u
+#define RTX_WREF_TRI    0x40000000u
+#define RTX_WREF_SPHERE 0x80000000u
+#define RTX_WREF_EMPTY  0xC0000000u
+#define RTX_WREF_KIND   0xC0000000u
+#define RTX_WREF_INDEX  0x3FFFFFFFu
+struct alignas(64) DBoxList {
+    float lo[3][RTX_WIDE];
+    float hi[3][RTX_WIDE];
+    uint32_t ref[RTX_WIDE];
+};
+
 // Intersection record of a triangle: 3 vertices (triangle.rs:90) + ids, 80 B, 16-B aligned.
 struct alignas(16) DTri {
     double v[9];
@@ -75,6 +91,7 @@ struct DScene {
     const DNode32 *nodes32;
     const DEntry32 *entries32;  // same order as leaf_refs
     const int32_t *leaf_refs;   // >= 0: triangle index, < 0: ~sphere index
+    const DBoxList *wide;       // 16-wide box lists over the finite prims; node 0 = root
     const DTri *tris;
     const DTriShade *tri_shade;
     const DSphere *spheres;

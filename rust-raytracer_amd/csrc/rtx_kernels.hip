@@ -517,6 +517,9 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
             }
         } else {
             const DEntry32 *ep = sc.entries32 + link;
+#ifdef RTX_EXP_NOE
+            if (MODE == MODE_ANY && aux) continue;   // timing experiment only: drop the leaf entry loop (wrong images)
+#endif
             for (uint32_t e = 0; e < aux; ++e) {
                 const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
                 const float4 ea = eq[0], eb = eq[1];
@@ -531,6 +534,9 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
                     if (!(lo <= hi)) continue;
                 }
                 const int ref = __float_as_int(eb.z);
+#ifdef RTX_EXP_NOX
+                if (MODE == MODE_ANY) continue;   // timing experiment only: drop the exact tests (wrong images)
+#endif
                 if (ref == last_ref0 || ref == last_ref1) continue;   // already tested with a window at least as wide
                 last_ref1 = last_ref0;
                 last_ref0 = ref;
@@ -1036,8 +1042,11 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
 // K4 trace_shadow: Renderer::shadow_intensity (renderer.rs:188-221), one feeler per lane; the
 // `tries` feelers of one (hit, light) pair sit in adjacent lanes and are reduced with
 // cross-lane shuffles before ONE set of atomics per group.
+#ifndef RTX_SHADOW_WAVES
+#define RTX_SHADOW_WAVES 1
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+__global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
     init_lds(s_stk);
@@ -1078,6 +1087,303 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow(DScene sc, DFrame fr, DSha
     double inv_tries = 1.0 / (double)tries;
     if (pow2_tries) {
         // groups are lane-aligned (tries divides 64 and RTX_BLOCK): butterfly sum over the group
+        for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
+            v.x += __shfl_xor(v.x, (int)off);
+            v.y += __shfl_xor(v.y, (int)off);
+            v.z += __shfl_xor(v.z, (int)off);
+        }
+        if (valid && k == 0u) acc_add(acc, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
+    } else if (valid) {
+        acc_add(acc, sample, w * scale(v, inv_tries));
+    }
+}
+
+// K4' cooperative any-hit shadows over the 16-wide box lists (all-opaque scenes).
+//
+// 16 consecutive lanes (with shadow_samples = 16: the 16 feelers of one hit point towards one
+// light) walk the hierarchy TOGETHER: the group keeps one stack in LDS, every step each lane
+// tests ONE of the node's 16 child boxes against the group's BEAM — the hull of the 16 rays,
+// origins in [omin, omax], inverse directions in [imin, imax] per axis — and a ballot turns the 16
+// answers into "children to push" and "primitives to test".  Primitives that the beam touches
+// are queued in LDS and then tested by every lane against its OWN ray: conservative f32 box
+// test, then the reference's exact f64 entry-bbox and primitive tests (octree.rs:170,
+// renderer.rs:212), so the per-ray answer is the exact any-hit answer.  A beam test is interval
+// arithmetic, hence conservative; an axis on which the group's directions change sign is left
+// unconstrained.
+#define RTX_COOP_STACK 128
+#define RTX_COOP_QUEUE 32
+#ifndef RTX_COOP_QT
+#define RTX_COOP_QT 6      // drain the candidate queue once it holds this many primitives
+#endif
+#ifndef RTX_COOP_WAVES
+#define RTX_COOP_WAVES 4
+#endif
+DEV float f32_below(double v) {   // a float <= v
+    float f = (float)v;
+    return f - fabsf(f) * 1.1920929e-7f;
+}
+DEV float grp_min(float v) {
+    v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2));
+    v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 8));
+    return v;
+}
+DEV float grp_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+__global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
+                                                                            uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
+                                                                            DCounters *counters, double *acc) {
+    __shared__ uint32_t s_stack[RTX_BLOCK / 16][RTX_COOP_STACK];
+    __shared__ uint32_t s_queue[RTX_BLOCK / 16][RTX_COOP_QUEUE];
+    uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
+    bool valid = group < n_groups;
+    size_t qc = sq.cap;
+    V3 hp = v3(0, 0, 0), w = v3(0, 0, 0);
+    uint64_t key = 0;
+    uint32_t sample = 0;
+    if (valid) {
+        const double *f = sq.f + (size_t)light * 6 * qc + group;
+        hp = v3(f[0 * qc], f[1 * qc], f[2 * qc]);
+        w = v3(f[3 * qc], f[4 * qc], f[5 * qc]);
+        key = sq.key[(size_t)light * qc + group];
+        sample = sq.sample[(size_t)light * qc + group];
+    }
+    count_rays(valid, &counters->rays[RAY_SHADOW]);
+
+    // the lane's own feeler, exactly as k_shadow builds it (renderer.rs:198-206)
+    Ray r = make_ray(v3(0, 0, 0), v3(0, 0, 1));
+    double distance_to_light = 0.0;
+    if (valid) {
+        const rtx_light &lt = sc.lights[light];
+        V3 sampled = v3(lt.position[0], lt.position[1], lt.position[2]);
+        if (lt.kind != RTX_LIGHT_POINT) {                                                // spherelight.rs:13-23
+            double ux, uy, uz, un;
+            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k, &ux, &uy);
+            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k + 1u, &uz, &un);
+            V3 jitter = v3(lt.radius * (ux - 0.5), lt.radius * (uy - 0.5), lt.radius * (uz - 0.5));
+            sampled = sampled + jitter;
+        }
+        V3 shadow_l = unit(sampled - hp);
+        r = make_ray(hp, shadow_l);
+        distance_to_light = len(sampled - hp);
+    }
+
+    // ---- own ray in f32 (as traverse_fast) for the per-lane primitive box tests
+    const double orx = r.ox - sc.centre[0], ory = r.oy - sc.centre[1], orz = r.oz - sc.centre[2];
+    const bool sx = r.sx, sy = r.sy, sz = r.sz;
+    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    float cnx, cfx, cny, cfy, cnz, cfz;
+    {
+        const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+        const double delta = big * (1.0 / 1048576.0);
+        const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
+        const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+        cnx = cx - hx; cfx = cx + hx; cny = cy - hy; cfy = cy + hy; cnz = cz - hz; cfz = cz + hz;
+    }
+    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
+    const float tmax_own = f32_above(distance_to_light);
+
+    // ---- the group's beam, as a frustum along its dominant axis a0 (the axis with the largest
+    // |direction| that every ray of the group travels in the same sense).  With u = distance along
+    // a0 from the origin, ray k is at  o_b + u * m_b  on each other axis b, m_b = d_b / d_a0; the
+    // beam is  [obmin + u * mL_b, obmax + u * mH_b]  for u >= 0.  A box is kept if its u range
+    // (clipped to [0, umax]) is non-empty and on both other axes the beam's extent over that u
+    // range overlaps the box: exact per axis pair, conservative overall.
+    const float INF = __int_as_float(0x7F800000);
+    const uint32_t lane = threadIdx.x & 63u, l16 = lane & 15u, gbase = lane & 48u, sub = threadIdx.x >> 4;
+    const double dd[3] = {r.dx, r.dy, r.dz}, oo[3] = {orx, ory, orz};
+    // smallest |d_a| over the group per axis (0 if the sign is mixed): the dominant axis maximises it
+    float dmin[3];
+    bool gneg[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = grp_min(valid ? (float)dd[a] : INF), hi = grp_max(valid ? (float)dd[a] : -INF);
+        dmin[a] = lo > 0.0f ? lo : (hi < 0.0f ? -hi : 0.0f);
+        gneg[a] = hi < 0.0f;
+    }
+    int a0 = dmin[0] >= dmin[1] ? (dmin[0] >= dmin[2] ? 0 : 2) : (dmin[1] >= dmin[2] ? 1 : 2);
+#ifdef RTX_COOP_NOBEAM
+    const bool beam_ok = false;                     // debugging: keep every box
+#else
+    const bool beam_ok = dmin[a0] > 1.0e-3f;       // else (mixed directions): every box is kept
+#endif
+    const int a1 = a0 == 0 ? 1 : 0, a2 = a0 == 2 ? 1 : 2;
+    const double d0 = a0 == 0 ? dd[0] : (a0 == 1 ? dd[1] : dd[2]);
+    const double o0 = a0 == 0 ? oo[0] : (a0 == 1 ? oo[1] : oo[2]);
+    const double d1 = a1 == 0 ? dd[0] : dd[1], o1 = a1 == 0 ? oo[0] : oo[1];
+    const double d2 = a2 == 1 ? dd[1] : dd[2], o2 = a2 == 1 ? oo[1] : oo[2];
+    // the sense of travel along a0, from the group reduction: lanes without a ray of their own
+    // (tail of the launch) still test boxes for the group and must agree with it
+    const bool neg0 = a0 == 0 ? gneg[0] : (a0 == 1 ? gneg[1] : gneg[2]);
+    // u = s0 * (coord - origin), s0 = +-1; origin interval along a0, widened below
+    float o0min = grp_min(valid ? f32_below(o0) : INF), o0max = grp_max(valid ? f32_above(o0) : -INF);
+    float o1min = grp_min(valid ? f32_below(o1) : INF), o1max = grp_max(valid ? f32_above(o1) : -INF);
+    float o2min = grp_min(valid ? f32_below(o2) : INF), o2max = grp_max(valid ? f32_above(o2) : -INF);
+    const double inv0 = 1.0 / fabs(d0);
+    float m1L = grp_min(valid ? f32_below(d1 * inv0) : INF), m1H = grp_max(valid ? f32_above(d1 * inv0) : -INF);
+    float m2L = grp_min(valid ? f32_below(d2 * inv0) : INF), m2H = grp_max(valid ? f32_above(d2 * inv0) : -INF);
+    const float umax = grp_max(valid ? f32_above(distance_to_light * fabs(d0)) : 0.0f);
+    {
+        float big = fmaxf(fmaxf(fmaxf(fabsf(o0min), fabsf(o0max)), fmaxf(fabsf(o1min), fabsf(o1max))), fmaxf(fabsf(o2min), fabsf(o2max))) +
+                    (float)sc.radius;
+        float delta = big * (1.0f / 1048576.0f) * 1.0001f;
+        // u <= 2*big, so a product u*m carries at most 2*big*|m|*2^-24 of rounding, and the rounding of
+        // u itself (<= big*2^-23) is scaled by |m|: fold both into the origin intervals, 4x over
+        float mmax = fmaxf(fmaxf(fabsf(m1L), fabsf(m1H)), fmaxf(fabsf(m2L), fabsf(m2H)));
+        float slack = delta + big * mmax * 1.0e-6f;
+        o0min -= delta; o0max += delta;
+        o1min -= slack; o1max += slack;
+        o2min -= slack; o2max += slack;
+    }
+    const float umax_w = umax * 1.000001f + (o0max - o0min);
+    volatile uint32_t *stack = s_stack[sub];
+    volatile uint32_t *queue = s_queue[sub];
+    const uint32_t NONE = 0xFFFFFFFFu;
+    const uint32_t below = (1u << l16) - 1u;
+    bool alive = valid;
+    uint32_t a16 = (uint32_t)(__ballot(alive) >> gbase) & 0xFFFFu;
+    uint32_t node = a16 ? 0u : NONE;
+    uint32_t sp = 0, qn = 0;
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
+
+    for (;;) {
+        const bool g_on = node != NONE;
+        if (!__any(g_on)) break;
+        bool hit = false, is_node = false;
+        if (g_on) {
+            const DBoxList *nd = sc.wide + node;
+            const uint32_t ref = nd->ref[l16];
+            WORK(++w_nodes;)
+            // u range of the box along a0
+            const float c0l = nd->lo[a0][l16], c0h = nd->hi[a0][l16];
+            const float c1l = nd->lo[a1][l16], c1h = nd->hi[a1][l16];
+            const float c2l = nd->lo[a2][l16], c2h = nd->hi[a2][l16];
+            float u0 = neg0 ? (o0min - c0h) : (c0l - o0max);      // smallest u at which any ray can be inside
+            float u1 = neg0 ? (o0max - c0l) : (c0h - o0min);      // largest
+            u0 = fmaxf(u0, 0.0f);
+            u1 = fminf(u1, umax_w);
+            // beam extent on a1, a2 over [u0, u1]
+            const float b1lo = o1min + fminf(u0 * m1L, u1 * m1L), b1hi = o1max + fmaxf(u0 * m1H, u1 * m1H);
+            const float b2lo = o2min + fminf(u0 * m2L, u1 * m2L), b2hi = o2max + fmaxf(u0 * m2H, u1 * m2H);
+#ifdef RTX_COOP_CHECK
+            const bool keep_beam = (u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l);
+            const bool keep = true;
+#else
+            const bool keep = (u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l) || !beam_ok;
+#endif
+            const uint32_t kind = ref & RTX_WREF_KIND;
+            hit = keep && kind != RTX_WREF_EMPTY;
+            is_node = kind == RTX_WREF_NODE;
+            const uint32_t h16 = (uint32_t)(__ballot(hit) >> gbase) & 0xFFFFu;
+            const uint32_t n16 = (uint32_t)(__ballot(hit && is_node) >> gbase) & 0xFFFFu;
+            const uint32_t p16 = h16 & ~n16;
+            if (sp + __popc(n16) > RTX_COOP_STACK) {
+                counters->overflow = 1u;      // cannot happen for depth * 15 < RTX_COOP_STACK (checked on the host)
+            } else {
+                if (hit && is_node) stack[sp + __popc(n16 & below)] = ref & RTX_WREF_INDEX;
+                sp += __popc(n16);
+            }
+#ifdef RTX_COOP_CHECK
+            if (hit && !is_node) queue[qn + __popc(p16 & below)] = (node << 4) | l16 | ((keep_beam || !beam_ok) ? 0u : 0x80000000u);
+#else
+            if (hit && !is_node) queue[qn + __popc(p16 & below)] = (node << 4) | l16;
+#endif
+            qn += __popc(p16);
+        }
+        // ---- drain the candidate queues: every lane tests the primitive against its OWN ray
+        const bool want_x = g_on && (qn >= RTX_COOP_QT || (sp == 0u && qn > 0u));
+        if (__any(want_x)) {
+            while (__any(qn > 0u)) {
+                if (qn > 0u) {
+                    --qn;
+#ifdef RTX_COOP_CHECK
+                    const uint32_t c_raw = queue[qn];
+                    const uint32_t c = c_raw & 0x7FFFFFFFu;
+                    const bool was_alive = alive;
+#else
+                    const uint32_t c = queue[qn];
+#endif
+                    if (alive) {
+                        const DBoxList *nd = sc.wide + (c >> 4);
+                        const uint32_t slot = c & 15u;
+                        const uint32_t ref = nd->ref[slot];
+                        const float lx = nd->lo[0][slot], ly = nd->lo[1][slot], lz = nd->lo[2][slot];
+                        const float ux = nd->hi[0][slot], uy = nd->hi[1][slot], uz = nd->hi[2][slot];
+                        WORK(++w_entries;)
+                        const float enx = sx ? lx : ux, efx = sx ? ux : lx;
+                        const float eny = sy ? ly : uy, efy = sy ? uy : ly;
+                        const float enz = sz ? lz : uz, efz = sz ? uz : lz;
+                        const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
+                        const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), tmax_own), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
+                        if (lo <= hi) {
+                            bool surely_in = false;
+                            if (finite_dir) {
+                                const float li = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
+                                const float hi2 = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
+                                surely_in = li <= hi2 && hi2 > 0.0f;
+                            }
+                            const uint32_t idx = ref & RTX_WREF_INDEX;
+                            if ((ref & RTX_WREF_KIND) == RTX_WREF_TRI) {
+                                int pid, mat;
+                                TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
+                                if (surely_in || tri_bbox_hit(tr, r)) {
+                                    WORK(++w_prims;)
+                                    double t, be, ga;
+                                    if (tri_hit(tr, r, EPSILON, distance_to_light, &t, &be, &ga)) alive = false;
+                                }
+                            } else {
+                                const DSphere &sp_ = sc.spheres[idx];
+                                V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                                if (surely_in || sphere_bbox_hit(cc, sp_.r, r)) {
+                                    WORK(++w_prims;)
+                                    double t;
+                                    if (sphere_hit(cc, sp_.r, r, EPSILON, distance_to_light, &t)) alive = false;
+                                }
+                            }
+                        }
+                    }
+#ifdef RTX_COOP_CHECK
+                    if (was_alive && !alive && (c_raw & 0x80000000u)) {
+                        const DBoxList *nd = sc.wide + (c >> 4);
+                        const uint32_t slot = c & 15u;
+                        if (atomicAdd(&counters->work[0][0], 1ull) < 4ull)
+                            printf("VIOLATION a0=%d neg0=%d o=(%g %g %g) d=(%g %g %g) dist=%g box=(%g %g %g)-(%g %g %g) o0=[%g %g] o1=[%g %g] o2=[%g %g] m1=[%g %g] m2=[%g %g] umax=%g\n",
+                                   a0, (int)neg0, orx, ory, orz, r.dx, r.dy, r.dz, distance_to_light, nd->lo[0][slot], nd->lo[1][slot], nd->lo[2][slot],
+                                   nd->hi[0][slot], nd->hi[1][slot], nd->hi[2][slot], o0min, o0max, o1min, o1max, o2min, o2max, m1L, m1H, m2L, m2H, umax_w);
+                    }
+#endif
+                }
+            }
+            a16 = (uint32_t)(__ballot(alive) >> gbase) & 0xFFFFu;
+            if (!a16) sp = 0u;   // every feeler of the group is occluded
+        }
+        node = NONE;
+        if (g_on && sp > 0u) {
+            --sp;
+            node = stack[sp];
+        }
+    }
+
+    // infinite prims (planes), octree.rs:163-165: a feeler that is still clear tests them in order
+    if (alive) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            double t;
+            if (plane_hit(sc.planes[p], r, EPSILON, distance_to_light, &t)) { alive = false; break; }
+        }
+    }
+#ifdef RTX_COUNT_WORK
+    if (valid) {
+        atomicAdd(&counters->work[1][0], (unsigned long long)w_nodes);
+        atomicAdd(&counters->work[1][1], (unsigned long long)w_entries);
+        atomicAdd(&counters->work[1][2], (unsigned long long)w_prims);
+    }
+#endif
+    V3 v = (valid && alive) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+    double inv_tries = 1.0 / (double)tries;
+    if (pow2_tries) {
         for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
             v.x += __shfl_xor(v.x, (int)off);
             v.y += __shfl_xor(v.y, (int)off);
@@ -1181,7 +1487,10 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     if (n_groups == 0 || tries == 0) return;
     uint32_t pow2 = (tries <= 64u && (tries & (tries - 1u)) == 0u) ? 1u : 0u;
     uint64_t lanes = (uint64_t)n_groups * tries;
-    if (sc.all_opaque)
+    if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP))
+        hipLaunchKernelGGL(k_shadow_coop, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, n_groups,
+                           tries, pow2, counters, acc);
+    else if (sc.all_opaque)
         hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     else

@@ -217,6 +217,8 @@ struct Work {
     DShadowQ sq{};
     DCounters *d_counters = nullptr;
     DCounters *h_up = nullptr, *h_back = nullptr;   // pinned
+    unsigned long long (*d_ray_slots)[16] = nullptr;
+    unsigned long long (*h_ray_slots)[16] = nullptr; // pinned
     double *acc = nullptr;
     size_t acc_cap = 0;       // samples
     uint8_t *out_rgba = nullptr;
@@ -267,6 +269,8 @@ void free_work(Work &w) {
     if (w.sq.key) hipFree(w.sq.key);
     if (w.sq.sample) hipFree(w.sq.sample);
     if (w.d_counters) hipFree(w.d_counters);
+    if (w.d_ray_slots) hipFree(w.d_ray_slots);
+    if (w.h_ray_slots) hipHostFree(w.h_ray_slots);
     if (w.h_up) hipHostFree(w.h_up);
     if (w.h_back) hipHostFree(w.h_back);
     if (w.acc) hipFree(w.acc);
@@ -301,6 +305,8 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         if ((st = dev_alloc(&w.d_counters, 1))) return st;
         HIPCHECK(hipHostMalloc((void **)&w.h_up, sizeof(DCounters), hipHostMallocDefault));
         HIPCHECK(hipHostMalloc((void **)&w.h_back, sizeof(DCounters), hipHostMallocDefault));
+        HIPCHECK(hipMalloc((void **)&w.d_ray_slots, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long)));
+        HIPCHECK(hipHostMalloc((void **)&w.h_ray_slots, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long), hipHostMallocDefault));
     }
     if (w.acc_cap < n_samples) {
         if (w.acc) { hipFree(w.acc); w.acc = nullptr; w.acc_cap = 0; }
@@ -417,7 +423,10 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
 
     if (n_samples) HIPCHECK(hipMemsetAsync(w.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));
     std::memset(w.h_up, 0, sizeof(DCounters));
+    w.h_up->ray_slots = w.d_ray_slots;
+    HIPCHECK(hipMemsetAsync(w.d_ray_slots, 0, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long), stream));
     HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, sizeof(DCounters), hipMemcpyHostToDevice, stream));
+    uint64_t shadow_rays = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     if (timing) {
         if ((st = next_event(&ev_first))) return st;
@@ -448,7 +457,7 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         w.h_up->pool_tail = top_end;
         w.h_up->overflow = 0;
         for (int li = 0; li < RTX_MAX_LIGHTS; ++li) w.h_up->shadow_tail[li] = 0;
-        HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, offsetof(DCounters, rays), hipMemcpyHostToDevice, stream));
+        HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, offsetof(DCounters, ray_slots), hipMemcpyHostToDevice, stream));
         Span sp_c{nullptr, nullptr, 0};
         if (timing) {
             if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b))) return st;
@@ -479,6 +488,7 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                 HIPCHECK(hipEventRecord(sp_s.a, stream));
             }
             rtxk_shadow(stream, s->d, fr, w.sq, (uint32_t)li, groups, tries, w.d_counters, w.acc);
+            shadow_rays += (uint64_t)groups * tries;                                             // one ray per try, renderer.rs:198
             ++launches_shadow;
             if (timing) {
                 HIPCHECK(hipEventRecord(sp_s.b, stream));
@@ -493,13 +503,16 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if ((st = next_event(&ev_last))) return st;
         HIPCHECK(hipEventRecord(ev_last, stream));
         HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipMemcpyAsync(w.h_ray_slots, w.d_ray_slots, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
         std::memset(stats, 0, sizeof(*stats));
-        stats->rays_primary = w.h_back->rays[RAY_PRIMARY];
-        stats->rays_reflect = w.h_back->rays[RAY_REFLECT];
-        stats->rays_gloss = w.h_back->rays[RAY_GLOSS];
-        stats->rays_refract = w.h_back->rays[RAY_REFRACT];
-        stats->rays_shadow = w.h_back->rays[RAY_SHADOW];
+        for (int sl = 0; sl < RTX_RAY_SLOTS; ++sl) {
+            stats->rays_primary += w.h_ray_slots[sl][RAY_PRIMARY];
+            stats->rays_reflect += w.h_ray_slots[sl][RAY_REFLECT];
+            stats->rays_gloss += w.h_ray_slots[sl][RAY_GLOSS];
+            stats->rays_refract += w.h_ray_slots[sl][RAY_REFRACT];
+        }
+        stats->rays_shadow = shadow_rays;
         for (int c = 0; c < 2; ++c)
             for (int k = 0; k < 3; ++k) stats->work[c][k] = w.h_back->work[c][k];
         float ms = 0.f;

@@ -9,6 +9,7 @@
 #define RTX_MAX_LIGHTS 16
 #define RTX_MAX_DEPTH 4095    // reflect/refract depth fits 12 bits of the ray flags
 #define RTX_BLOCK 256         // threads per workgroup = 4 wave64
+#define RTX_RAY_SLOTS 256
 
 // One octree node (octree.rs:51-56) in 64 bytes = one half cache line: the node's own bbox
 // (children's boxes are re-derived in registers with the reference's expressions,
@@ -154,7 +155,11 @@ struct DCounters {
     uint32_t pool_tail;
     uint32_t overflow;
     uint32_t shadow_tail[RTX_MAX_LIGHTS];
-    unsigned long long rays[5];
+    // closest-hit rays by type, counted one atomic per wave into RTX_RAY_SLOTS slots (one 128-B line
+    // each, slot = block index % RTX_RAY_SLOTS): tens of millions of atomics on ONE address would
+    // serialise at ~12 ns each and dominate the frame.  Shadow feelers are counted on the host
+    // (groups x tries per launch).
+    unsigned long long (*ray_slots)[16];
     // builds with -DRTX_COUNT_WORK only (librtx_count.so): [0] closest-hit rays, [1] shadow feelers;
     // nodes visited, leaf entries fetched, prim tests run
     unsigned long long work[2][3];

@@ -865,10 +865,13 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
     bool inside = (flags & RAYF_INSIDE) != 0u;
     uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
 
-    count_rays(valid && type == RAY_PRIMARY, &counters->rays[RAY_PRIMARY]);
-    count_rays(valid && type == RAY_REFLECT, &counters->rays[RAY_REFLECT]);
-    count_rays(valid && type == RAY_GLOSS, &counters->rays[RAY_GLOSS]);
-    count_rays(valid && type == RAY_REFRACT, &counters->rays[RAY_REFRACT]);
+    {
+        unsigned long long *slot = counters->ray_slots[blockIdx.x % RTX_RAY_SLOTS];
+        count_rays(valid && type == RAY_PRIMARY, slot + RAY_PRIMARY);
+        count_rays(valid && type == RAY_REFLECT, slot + RAY_REFLECT);
+        count_rays(valid && type == RAY_GLOSS, slot + RAY_GLOSS);
+        count_rays(valid && type == RAY_REFRACT, slot + RAY_REFRACT);
+    }
 
     Ray r = make_ray(o, d);
     Hit hit;
@@ -1064,7 +1067,6 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
         key = sq.key[(size_t)light * qc + group];
         sample = sq.sample[(size_t)light * qc + group];
     }
-    count_rays(valid, &counters->rays[RAY_SHADOW]);
 
     V3 v = v3(0, 0, 0);
     if (valid) {
@@ -1116,7 +1118,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
 #define RTX_COOP_QT 6      // drain the candidate queue once it holds this many primitives
 #endif
 #ifndef RTX_COOP_WAVES
-#define RTX_COOP_WAVES 4
+#define RTX_COOP_WAVES 5
 #endif
 DEV float f32_below(double v) {   // a float <= v
     float f = (float)v;
@@ -1151,7 +1153,6 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         key = sq.key[(size_t)light * qc + group];
         sample = sq.sample[(size_t)light * qc + group];
     }
-    count_rays(valid, &counters->rays[RAY_SHADOW]);
 
     // the lane's own feeler, exactly as k_shadow builds it (renderer.rs:198-206)
     Ray r = make_ray(v3(0, 0, 0), v3(0, 0, 1));

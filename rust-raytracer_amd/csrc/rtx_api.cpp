@@ -217,8 +217,11 @@ struct Work {
     DShadowQ sq{};
     DCounters *d_counters = nullptr;
     DCounters *h_up = nullptr, *h_back = nullptr;   // pinned
-    unsigned long long (*d_ray_slots)[16] = nullptr;
-    unsigned long long (*h_ray_slots)[16] = nullptr; // pinned
+    unsigned long long (*d_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr;
+    unsigned long long (*h_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr; // pinned
+    double *hit_t = nullptr;
+    int32_t *hit_ref = nullptr;
+    uint32_t hit_cap = 0;
     double *acc = nullptr;
     size_t acc_cap = 0;       // samples
     uint8_t *out_rgba = nullptr;
@@ -270,6 +273,8 @@ void free_work(Work &w) {
     if (w.sq.sample) hipFree(w.sq.sample);
     if (w.d_counters) hipFree(w.d_counters);
     if (w.d_ray_slots) hipFree(w.d_ray_slots);
+    if (w.hit_t) hipFree(w.hit_t);
+    if (w.hit_ref) hipFree(w.hit_ref);
     if (w.h_ray_slots) hipHostFree(w.h_ray_slots);
     if (w.h_up) hipHostFree(w.h_up);
     if (w.h_back) hipHostFree(w.h_back);
@@ -300,13 +305,19 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         if ((st = dev_alloc(&w.sq.sample, nl * (size_t)batch))) return st;
         w.sq.cap = batch;
     }
+    if (w.hit_cap < batch) {
+        if (w.hit_t) { hipFree(w.hit_t); hipFree(w.hit_ref); w.hit_t = nullptr; w.hit_ref = nullptr; w.hit_cap = 0; }
+        rtx_status st;
+        if ((st = dev_alloc(&w.hit_t, batch)) || (st = dev_alloc(&w.hit_ref, batch))) return st;
+        w.hit_cap = batch;
+    }
     if (!w.d_counters) {
         rtx_status st;
         if ((st = dev_alloc(&w.d_counters, 1))) return st;
         HIPCHECK(hipHostMalloc((void **)&w.h_up, sizeof(DCounters), hipHostMallocDefault));
         HIPCHECK(hipHostMalloc((void **)&w.h_back, sizeof(DCounters), hipHostMallocDefault));
-        HIPCHECK(hipMalloc((void **)&w.d_ray_slots, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long)));
-        HIPCHECK(hipHostMalloc((void **)&w.h_ray_slots, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHECK(hipMalloc((void **)&w.d_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)));
+        HIPCHECK(hipHostMalloc((void **)&w.h_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     }
     if (w.acc_cap < n_samples) {
         if (w.acc) { hipFree(w.acc); w.acc = nullptr; w.acc_cap = 0; }
@@ -424,9 +435,8 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     if (n_samples) HIPCHECK(hipMemsetAsync(w.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));
     std::memset(w.h_up, 0, sizeof(DCounters));
     w.h_up->ray_slots = w.d_ray_slots;
-    HIPCHECK(hipMemsetAsync(w.d_ray_slots, 0, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long), stream));
+    HIPCHECK(hipMemsetAsync(w.d_ray_slots, 0, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), stream));
     HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, sizeof(DCounters), hipMemcpyHostToDevice, stream));
-    uint64_t shadow_rays = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     if (timing) {
         if ((st = next_event(&ev_first))) return st;
@@ -456,20 +466,38 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         uint32_t begin = top.end - n;
         w.h_up->pool_tail = top_end;
         w.h_up->overflow = 0;
-        for (int li = 0; li < RTX_MAX_LIGHTS; ++li) w.h_up->shadow_tail[li] = 0;
         HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, offsetof(DCounters, ray_slots), hipMemcpyHostToDevice, stream));
         Span sp_c{nullptr, nullptr, 0};
         if (timing) {
             if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b))) return st;
             HIPCHECK(hipEventRecord(sp_c.a, stream));
         }
-        rtxk_trace(stream, s->d, fr, w.pool, begin, n, w.sq, w.d_counters, w.acc, d_ids);
+        rtxk_trace(stream, s->d, fr, w.pool, begin, n, w.sq, w.d_counters, w.acc, d_ids, w.hit_t, w.hit_ref);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));
             spans.push_back(sp_c);
         }
+        // the counters travel back while the shadow kernels run: the host only needs them (children
+        // spawned, overflow) to size the NEXT closest-hit launch
         HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+        // shadow groups sit at their ray's index (empty where the ray hit nothing): n groups per light
+        if (opt->shadow_samples > 0) {
+            for (size_t li = 0; li < s->lights.size(); ++li) {
+                uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194
+                Span sp_s{nullptr, nullptr, 1};
+                if (timing) {   // one event pair per launch, so ms_shadow / launches_shadow is a kernel duration
+                    if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
+                    HIPCHECK(hipEventRecord(sp_s.a, stream));
+                }
+                rtxk_shadow(stream, s->d, fr, w.sq, (uint32_t)li, n, tries, w.d_counters, w.acc);
+                ++launches_shadow;
+                if (timing) {
+                    HIPCHECK(hipEventRecord(sp_s.b, stream));
+                    spans.push_back(sp_s);
+                }
+            }
+        }
         HIPCHECK(hipStreamSynchronize(stream));
         if (w.h_back->overflow) return fail(RTX_ERR_QUEUE_OVERFLOW, "device queue overflow");
         top.end = begin;
@@ -477,24 +505,6 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         uint32_t children = w.h_back->pool_tail - top_end;
         if (children) segs.push_back(Seg{top_end, top_end + children});
         peak_pool = std::max<uint64_t>(peak_pool, (uint64_t)top_end + children);
-
-        for (size_t li = 0; li < s->lights.size(); ++li) {
-            uint32_t groups = w.h_back->shadow_tail[li];
-            if (!groups) continue;
-            uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194
-            Span sp_s{nullptr, nullptr, 1};
-            if (timing) {   // one event pair per launch, so ms_shadow / launches_shadow is a kernel duration
-                if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
-                HIPCHECK(hipEventRecord(sp_s.a, stream));
-            }
-            rtxk_shadow(stream, s->d, fr, w.sq, (uint32_t)li, groups, tries, w.d_counters, w.acc);
-            shadow_rays += (uint64_t)groups * tries;                                             // one ray per try, renderer.rs:198
-            ++launches_shadow;
-            if (timing) {
-                HIPCHECK(hipEventRecord(sp_s.b, stream));
-                spans.push_back(sp_s);
-            }
-        }
     }
     rtxk_resolve(stream, fr, w.acc, d_rgba);
     HIPCHECK(hipGetLastError());
@@ -503,7 +513,7 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if ((st = next_event(&ev_last))) return st;
         HIPCHECK(hipEventRecord(ev_last, stream));
         HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
-        HIPCHECK(hipMemcpyAsync(w.h_ray_slots, w.d_ray_slots, RTX_RAY_SLOTS * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipMemcpyAsync(w.h_ray_slots, w.d_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
         std::memset(stats, 0, sizeof(*stats));
         for (int sl = 0; sl < RTX_RAY_SLOTS; ++sl) {
@@ -511,8 +521,11 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             stats->rays_reflect += w.h_ray_slots[sl][RAY_REFLECT];
             stats->rays_gloss += w.h_ray_slots[sl][RAY_GLOSS];
             stats->rays_refract += w.h_ray_slots[sl][RAY_REFRACT];
+            for (size_t li = 0; li < s->lights.size(); ++li) {   // shadow groups emitted per light x tries (renderer.rs:194-198)
+                uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;
+                stats->rays_shadow += w.h_ray_slots[sl][RTX_RAY_SLOT_GROUPS + li] * tries;
+            }
         }
-        stats->rays_shadow = shadow_rays;
         for (int c = 0; c < 2; ++c)
             for (int k = 0; k < 3; ++k) stats->work[c][k] = w.h_back->work[c][k];
         float ms = 0.f;

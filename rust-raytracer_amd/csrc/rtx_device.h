@@ -10,6 +10,8 @@
 #define RTX_MAX_DEPTH 4095    // reflect/refract depth fits 12 bits of the ray flags
 #define RTX_BLOCK 256         // threads per workgroup = 4 wave64
 #define RTX_RAY_SLOTS 256
+#define RTX_RAY_SLOT_WORDS 32   // u64 per slot: [0..4] rays by type, [8..23] shadow groups emitted per light
+#define RTX_RAY_SLOT_GROUPS 8
 
 // One octree node (octree.rs:51-56) in 64 bytes = one half cache line: the node's own bbox
 // (children's boxes are re-derived in registers with the reference's expressions,
@@ -154,12 +156,12 @@ struct DShadowQ {
 struct DCounters {
     uint32_t pool_tail;
     uint32_t overflow;
-    uint32_t shadow_tail[RTX_MAX_LIGHTS];
+    uint32_t reserved_[RTX_MAX_LIGHTS];
     // closest-hit rays by type, counted one atomic per wave into RTX_RAY_SLOTS slots (one 128-B line
     // each, slot = block index % RTX_RAY_SLOTS): tens of millions of atomics on ONE address would
     // serialise at ~12 ns each and dominate the frame.  Shadow feelers are counted on the host
     // (groups x tries per launch).
-    unsigned long long (*ray_slots)[16];
+    unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS];
     // builds with -DRTX_COUNT_WORK only (librtx_count.so): [0] closest-hit rays, [1] shadow feelers;
     // nodes visited, leaf entries fetched, prim tests run
     unsigned long long work[2][3];
@@ -171,7 +173,7 @@ typedef void *rtx_stream_t;
 
 void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count);
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
-                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out);
+                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref);
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);

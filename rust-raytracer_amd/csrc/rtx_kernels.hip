@@ -834,16 +834,83 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
     pool_store(pool, slot, v3(fr.pos[0], fr.pos[1], fr.pos[2]), dir, v3(1.0, 1.0, 1.0), key, s, flags);
 }
 
-// K2+K3 (+K5): Ray::get_nearest_hit (ray.rs:44-66), then the body of Renderer::trace
-// (renderer.rs:108-144): local shading per light -> one shadow group per (hit, light);
-// reflection / gloss / transmission children -> ray pool; miss -> skybox / background.
+// K2 trace_closest: Ray::get_nearest_hit (ray.rs:44-66) for pool rays [begin, begin+count):
+// writes the winning t and primitive ref per ray.  Kept apart from the shading so that the
+// traversal runs at its own (higher) occupancy.
+#ifndef RTX_CLOSEST_WAVES
+#define RTX_CLOSEST_WAVES 5
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
-                                                      DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out) {
+__global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
+                                                                          DCounters *counters, double *hit_t, int32_t *hit_ref) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
     init_lds(s_stk);
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
+    uint32_t slot = begin + (valid ? gid : 0u);
+    uint32_t flags = valid ? pool.flags[slot] : RAYF_DEAD;
+    valid = valid && !(flags & RAYF_DEAD);
+    uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
+    {
+        unsigned long long *cs = counters->ray_slots[blockIdx.x % RTX_RAY_SLOTS];
+        count_rays(valid && type == RAY_PRIMARY, cs + RAY_PRIMARY);
+        count_rays(valid && type == RAY_REFLECT, cs + RAY_REFLECT);
+        count_rays(valid && type == RAY_GLOSS, cs + RAY_GLOSS);
+        count_rays(valid && type == RAY_REFRACT, cs + RAY_REFRACT);
+    }
+    Hit hit;
+    hit.t = inf();
+    hit.ref = REF_NONE;
+    WORK(hit.w_nodes = hit.w_entries = hit.w_prims = 0;)
+    if (valid) {
+        size_t cap = pool.cap;
+        const double *f = pool.f + slot;
+        Ray r = make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]));
+        V3 unused;
+        traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
+    }
+    WORK(count_work(valid, hit, counters->work[0]);)
+    if (gid < count) {
+        hit_t[gid] = hit.t;
+        hit_ref[gid] = valid ? hit.ref : REF_NONE;
+    }
+}
+
+// Block-wide allocation of `c` consecutive slots per lane from a global counter: one atomic per
+// workgroup (a per-wave atomic on one address serialises at the memory side).  Every thread of
+// the block must call it.
+DEV uint32_t block_alloc(uint32_t c, uint32_t *counter, uint32_t *s_tmp /* >= 6 words of LDS */) {
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6;
+    uint32_t x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = (uint32_t)__shfl_up((int)x, off);
+        if ((int)lane >= off) x += y;
+    }
+    if (lane == 63u) s_tmp[wid] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+        s_tmp[4] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_tmp[4];
+    for (uint32_t wv = 0; wv < wid; ++wv) base += s_tmp[wv];
+    return base + x - c;
+}
+
+// K3 (+K5) shade_and_spawn: the body of Renderer::trace after the closest-hit search
+// (renderer.rs:108-144): local shading per light -> one shadow group per (ray, light) at the
+// ray's own index (no compaction, no atomics; a ray without a hit marks its group empty);
+// reflection / gloss / transmission children -> ray pool; miss -> skybox / background.
+#define SHADOW_GROUP_EMPTY 0xFFFFFFFFu
+__global__ void __launch_bounds__(RTX_BLOCK) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
+                                                     const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
+                                                     double *acc, int32_t *prim_id_out) {
+    __shared__ uint32_t s_tmp[8];
+    uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    bool in_range = gid < count;
+    bool valid = in_range;
     uint32_t slot = begin + (valid ? gid : 0u);
     uint32_t flags = valid ? pool.flags[slot] : RAYF_DEAD;
     valid = valid && !(flags & RAYF_DEAD);
@@ -852,6 +919,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(0, 0, 0);
     uint64_t key = 0;
     uint32_t sample = 0;
+    Hit hit;
+    hit.t = inf();
+    hit.ref = REF_NONE;
     if (valid) {
         const double *f = pool.f + slot;
         o = v3(f[0 * cap], f[1 * cap], f[2 * cap]);
@@ -859,28 +929,14 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
         thr = v3(f[6 * cap], f[7 * cap], f[8 * cap]);
         key = pool.key[slot];
         sample = pool.sample[slot];
+        hit.t = hit_t[gid];
+        hit.ref = hit_ref[gid];
     }
     uint32_t reflect_depth = (flags >> RAYF_REFLECT_SHIFT) & RAYF_DEPTH_MASK;
     uint32_t refract_depth = (flags >> RAYF_REFRACT_SHIFT) & RAYF_DEPTH_MASK;
     bool inside = (flags & RAYF_INSIDE) != 0u;
     uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
-
-    {
-        unsigned long long *slot = counters->ray_slots[blockIdx.x % RTX_RAY_SLOTS];
-        count_rays(valid && type == RAY_PRIMARY, slot + RAY_PRIMARY);
-        count_rays(valid && type == RAY_REFLECT, slot + RAY_REFLECT);
-        count_rays(valid && type == RAY_GLOSS, slot + RAY_GLOSS);
-        count_rays(valid && type == RAY_REFRACT, slot + RAY_REFRACT);
-    }
-
     Ray r = make_ray(o, d);
-    Hit hit;
-    hit.t = inf();
-    hit.ref = REF_NONE;
-    V3 unused;
-    WORK(hit.w_nodes = hit.w_entries = hit.w_prims = 0;)
-    if (valid) traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
-    WORK(count_work(valid, hit, counters->work[0]);)
 
     bool is_hit = valid && hit.ref != REF_NONE;
 
@@ -942,8 +998,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
         iv = unit(-d);
     }
     for (int li = 0; li < sc.n_lights; ++li) {
-        V3 w = v3(0, 0, 0);
         bool emit = false;
+        V3 w = v3(0, 0, 0);
         if (is_hit) {
             const rtx_light &lt = sc.lights[li];
             V3 l = unit(v3(lt.position[0], lt.position[1], lt.position[2]) - hp);
@@ -952,17 +1008,15 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
             if (fr.shadow_samples == 0u) acc_add(acc, sample, w);                        // renderer.rs:191: shadow = one
             else emit = true;
         }
-        uint32_t gslot = wave_append(emit, &counters->shadow_tail[li]);
-        if (emit) {
-            if (gslot < sq.cap) {
-                size_t qc = sq.cap;
-                double *f = sq.f + (size_t)li * 6 * qc + gslot;
+        if (fr.shadow_samples != 0u) count_rays(emit, counters->ray_slots[blockIdx.x % RTX_RAY_SLOTS] + RTX_RAY_SLOT_GROUPS + li);
+        if (in_range && fr.shadow_samples != 0u) {
+            size_t qc = sq.cap;
+            sq.sample[(size_t)li * qc + gid] = emit ? sample : SHADOW_GROUP_EMPTY;
+            if (emit) {
+                double *f = sq.f + (size_t)li * 6 * qc + gid;
                 f[0 * qc] = hp.x; f[1 * qc] = hp.y; f[2 * qc] = hp.z;
                 f[3 * qc] = w.x; f[4 * qc] = w.y; f[5 * qc] = w.z;
-                sq.key[(size_t)li * qc + gslot] = key;
-                sq.sample[(size_t)li * qc + gslot] = sample;
-            } else {
-                counters->overflow = 1u;
+                sq.key[(size_t)li * qc + gid] = key;
             }
         }
     }
@@ -977,68 +1031,53 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_trace(DScene sc, DFrame fr, DPool
     // a child whose depth counter reaches 0 returns zero at renderer.rs:106 and is not a ray
     bool spawn_reflect = reflective && reflect_depth > 1u && refract_depth > 0u;
     bool glossy = m.kind != RTX_MAT_FLAT && m.glossiness > F64_EPSILON;
+    bool spawn_transmit = refractive && refract_depth > 1u && reflect_depth > 0u;
+    uint32_t n_reflect = spawn_reflect ? (glossy ? fr.gloss_samples : 1u) : 0u;
+    uint32_t n_children = n_reflect + (spawn_transmit ? 1u : 0u);
+    uint32_t cs = block_alloc(n_children, &counters->pool_tail, s_tmp);
+    if (n_children && cs + n_children > pool.cap) {
+        counters->overflow = 1u;
+        n_reflect = 0u;
+        spawn_transmit = false;
+    }
     V3 rdir = v3(0, 0, 1);
     if (spawn_reflect) rdir = reflect(iv, n);
     uint32_t child_flags_reflect = ((reflect_depth - 1u) << RAYF_REFLECT_SHIFT) | (refract_depth << RAYF_REFRACT_SHIFT) |
                                    (inside ? RAYF_INSIDE : 0u);
-    {   // mirror reflection (renderer.rs:164)
-        bool want = spawn_reflect && !glossy;
-        uint32_t cs = wave_append(want, &counters->pool_tail);
-        if (want) {
-            if (cs < pool.cap)
-                pool_store(pool, cs, hp, rdir, scale(scale(thr, m.k_sg), reflect_fresnel), child_key(key, CODE_MIRROR), sample,
-                           child_flags_reflect | ((uint32_t)RAY_REFLECT << RAYF_TYPE_SHIFT));
-            else counters->overflow = 1u;
-        }
-    }
-    if (__any(spawn_reflect && glossy)) {   // glossy reflection: gloss_samples perturbed rays, averaged (renderer.rs:155-161)
+    if (n_reflect && !glossy) {   // mirror reflection (renderer.rs:164)
+        pool_store(pool, cs, hp, rdir, scale(scale(thr, m.k_sg), reflect_fresnel), child_key(key, CODE_MIRROR), sample,
+                   child_flags_reflect | ((uint32_t)RAY_REFLECT << RAYF_TYPE_SHIFT));
+    } else if (n_reflect) {       // glossy reflection: gloss_samples perturbed rays, averaged (renderer.rs:155-161)
         double inv_g = 1.0 / (double)fr.gloss_samples;
-        for (uint32_t g = 0; g < fr.gloss_samples; ++g) {
-            bool want = spawn_reflect && glossy;
-            V3 gdir = rdir;
-            uint64_t ck = 0;
-            if (want) {   // Ray::perturb (ray.rs:68-81) with Vec3::random (vec3.rs:112-126)
-                ck = child_key(key, CODE_GLOSS0 + g);
-                double u_phi, u_cos, u_r, un;
-                draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 0, &u_phi, &u_cos);
-                draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 1, &u_r, &un);
-                double phi = 0.0 + (2.0 * PI - 0.0) * u_phi;
-                double costheta = -1.0 + (1.0 - -1.0) * u_cos;
-                double uu = 0.0 + (1.0 - 0.0) * u_r;
-                double theta = acos(costheta);
-                double rr = pow(uu, 1.0 / 3.0);
-                V3 rand_vec = scale(v3(rr * sin(theta) * cos(phi), rr * sin(theta) * sin(phi), rr * cos(theta)), m.glossiness);
-                V3 corrected = dot(rand_vec, rdir) < 0.0 ? scale(rand_vec, -1.0) : rand_vec;
-                gdir = unit(corrected + rdir);
-            }
-            uint32_t cs = wave_append(want, &counters->pool_tail);
-            if (want) {
-                if (cs < pool.cap)
-                    pool_store(pool, cs, hp, gdir, scale(scale(scale(thr, inv_g), m.k_sg), reflect_fresnel), ck, sample,
-                               child_flags_reflect | ((uint32_t)RAY_GLOSS << RAYF_TYPE_SHIFT));
-                else counters->overflow = 1u;
-            }
+        for (uint32_t g = 0; g < n_reflect; ++g) {
+            // Ray::perturb (ray.rs:68-81) with Vec3::random (vec3.rs:112-126)
+            uint64_t ck = child_key(key, CODE_GLOSS0 + g);
+            double u_phi, u_cos, u_r, un;
+            draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 0, &u_phi, &u_cos);
+            draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 1, &u_r, &un);
+            double phi = 0.0 + (2.0 * PI - 0.0) * u_phi;
+            double costheta = -1.0 + (1.0 - -1.0) * u_cos;
+            double uu = 0.0 + (1.0 - 0.0) * u_r;
+            double theta = acos(costheta);
+            double rr = pow(uu, 1.0 / 3.0);
+            V3 rand_vec = scale(v3(rr * sin(theta) * cos(phi), rr * sin(theta) * sin(phi), rr * cos(theta)), m.glossiness);
+            V3 corrected = dot(rand_vec, rdir) < 0.0 ? scale(rand_vec, -1.0) : rand_vec;
+            V3 gdir = unit(corrected + rdir);
+            pool_store(pool, cs + g, hp, gdir, scale(scale(scale(thr, inv_g), m.k_sg), reflect_fresnel), ck, sample,
+                       child_flags_reflect | ((uint32_t)RAY_GLOSS << RAYF_TYPE_SHIFT));
         }
     }
-    {   // transmission (renderer.rs:170-186): TIR -> mirror direction with weight 1.0, `!inside` either way
-        bool want = refractive && refract_depth > 1u && reflect_depth > 0u;
+    if (spawn_transmit) {   // transmission (renderer.rs:170-186): TIR -> mirror direction with weight 1.0, `!inside` either way
         V3 tdir = v3(0, 0, 1);
         double actual = refract_fresnel;
-        if (want) {
-            if (!refract(iv, n, m.ior, inside, &tdir)) {
-                tdir = reflect(iv, n);
-                actual = 1.0;
-            }
+        if (!refract(iv, n, m.ior, inside, &tdir)) {
+            tdir = reflect(iv, n);
+            actual = 1.0;
         }
-        uint32_t cs = wave_append(want, &counters->pool_tail);
-        if (want) {
-            uint32_t cf = (reflect_depth << RAYF_REFLECT_SHIFT) | ((refract_depth - 1u) << RAYF_REFRACT_SHIFT) |
-                          (inside ? 0u : RAYF_INSIDE) | ((uint32_t)RAY_REFRACT << RAYF_TYPE_SHIFT);
-            if (cs < pool.cap)
-                pool_store(pool, cs, hp + scale(tdir, EPSILON), tdir, scale(scale(thr, m.k_tg), actual),
-                           child_key(key, CODE_TRANSMIT), sample, cf);
-            else counters->overflow = 1u;
-        }
+        uint32_t cf = (reflect_depth << RAYF_REFLECT_SHIFT) | ((refract_depth - 1u) << RAYF_REFRACT_SHIFT) |
+                      (inside ? 0u : RAYF_INSIDE) | ((uint32_t)RAY_REFRACT << RAYF_TYPE_SHIFT);
+        pool_store(pool, cs + n_reflect, hp + scale(tdir, EPSILON), tdir, scale(scale(thr, m.k_tg), actual),
+                   child_key(key, CODE_TRANSMIT), sample, cf);
     }
 }
 
@@ -1061,11 +1100,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
     uint64_t key = 0;
     uint32_t sample = 0;
     if (valid) {
+        sample = sq.sample[(size_t)light * qc + group];
+        valid = sample != SHADOW_GROUP_EMPTY;
+    }
+    if (valid) {
         const double *f = sq.f + (size_t)light * 6 * qc + group;
         hp = v3(f[0 * qc], f[1 * qc], f[2 * qc]);
         w = v3(f[3 * qc], f[4 * qc], f[5 * qc]);
         key = sq.key[(size_t)light * qc + group];
-        sample = sq.sample[(size_t)light * qc + group];
     }
 
     V3 v = v3(0, 0, 0);
@@ -1147,11 +1189,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     uint64_t key = 0;
     uint32_t sample = 0;
     if (valid) {
+        sample = sq.sample[(size_t)light * qc + group];
+        valid = sample != SHADOW_GROUP_EMPTY;
+    }
+    if (valid) {
         const double *f = sq.f + (size_t)light * 6 * qc + group;
         hp = v3(f[0 * qc], f[1 * qc], f[2 * qc]);
         w = v3(f[3 * qc], f[4 * qc], f[5 * qc]);
         key = sq.key[(size_t)light * qc + group];
-        sample = sq.sample[(size_t)light * qc + group];
     }
 
     // the lane's own feeler, exactly as k_shadow builds it (renderer.rs:198-206)
@@ -1474,14 +1519,16 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
     hipLaunchKernelGGL(k_generate, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, fr, pool, pool_base, s0, count);
 }
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
-                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out) {
+                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref) {
     if (count == 0) return;
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER)
-        hipLaunchKernelGGL(k_trace<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool,
-                           begin, count, sq, counters, acc, prim_id_out);
+        hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                           count, counters, hit_t, hit_ref);
     else
-        hipLaunchKernelGGL(k_trace<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin,
-                           count, sq, counters, acc, prim_id_out);
+        hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
+                           counters, hit_t, hit_ref);
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t, hit_ref,
+                       sq, counters, acc, prim_id_out);
 }
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc) {

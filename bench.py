@@ -86,15 +86,9 @@ def main():
     build_s = time.time() - t0
 
     n_blocks = H // 8
-    my_blocks = list(range(rank, n_blocks, world))
-    max_blocks = (n_blocks + world - 1) // world
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
-    blocks_view = rgba.view(n_blocks, 8 * W * 4)
-    compact = torch.zeros((max_blocks, 8 * W * 4), dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(compact) for _ in range(world)] if (world > 1 and rank == 0) else None
-    my_idx = torch.tensor(my_blocks, dtype=torch.long, device=dev)
-    final = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    final_blocks = final.view(n_blocks, 8 * W * 4) if rank == 0 else None
+    gat = pkg.sharding.StillGather(W, H, rank, world, dev)
+    final = gat.final
 
     opt = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
                       pixel_samples=ps, rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0,
@@ -103,15 +97,7 @@ def main():
 
     def step():
         st = scene.render_device(cam, opt, rgba.data_ptr(), None, stream, want_stats=True)
-        if world > 1:
-            compact[:len(my_blocks)] = blocks_view.index_select(0, my_idx)
-            dist.gather(compact, gathered, dst=0)            # RCCL over xGMI: <= 1.04 MB per rank at 1080p
-            if rank == 0:
-                for r in range(world):
-                    ids = list(range(r, n_blocks, world))
-                    final_blocks[r::world] = gathered[r][:len(ids)]
-        else:
-            final.copy_(rgba)
+        gat.gather(rgba, dist)           # RCCL over xGMI: <= 1.04 MB per rank at 1080p (no-op copy at N=1)
         return st
 
     def barrier():
@@ -205,11 +191,20 @@ def main():
                 kname, ms, launches, nrays, bpr = "k_trace", ms_closest, l_closest, float(closest_rays), b_closest
             avg_ms = ms / max(1.0, launches)
             achieved = bpr * (nrays / max(1.0, launches)) / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:   # HBM bytes per launch of that kernel from separate rocprofv3 --pmc passes (profiles/)
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                    traffic = json.load(fh).get(args.workload, {}).get(kname)
+            except (OSError, ValueError):
+                pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                                "avg_launch_ms": avg_ms, "launches_per_frame": launches,
                                "algorithmic_bytes_per_ray": bpr, "rays_per_launch": nrays / max(1.0, launches),
-                               "note": "reference-order algorithmic bytes (oracle counters); PMC traffic in profiles/"}
+                               "note": "achieved uses the REFERENCE-ORDER algorithmic bytes SURVEY.md 8d defines (oracle traversal "
+                                       "counters: every pierced leaf, no early-out), which the GPU kernels avoid touching by ordered, "
+                                       "culled, cooperative traversal, so frac > 1 is expected; traffic = measured HBM bytes per launch "
+                                       "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes, profiles/)"}
         print(json.dumps(out), flush=True)
 
     scene.close()

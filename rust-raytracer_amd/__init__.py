@@ -9,4 +9,4 @@ reference's Renderer (renderer.py).
 from . import abi, desc  # noqa: F401
 from .desc import SceneBuilder, camera, options  # noqa: F401
 from .renderer import Renderer, Scene, octree_dump  # noqa: F401,E402
-from . import host  # noqa: F401,E402
+from . import host, sharding  # noqa: F401,E402

@@ -768,6 +768,9 @@ DEV void count_work(bool valid, const Hit &h, unsigned long long *w) {
 }
 #endif
 DEV void acc_add(double *acc, uint32_t sample, V3 c) {
+#ifdef RTX_EXP_NOACC
+    if (c.x > -1.0) return;   // timing experiment only (wrong images)
+#endif
     double *p = acc + (size_t)sample * 3;
     unsafeAtomicAdd(p + 0, c.x);   // global_atomic_add_f64 on gfx950
     unsafeAtomicAdd(p + 1, c.y);

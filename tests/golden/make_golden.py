@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ with the CPU oracle (oracle/oracle.cpp, the
+literal restatement of the reference's trace loop).  The reference itself (Rust) cannot be built
+in this pipeline and holds no golden images, so these vectors pin the ORACLE's behaviour
+("restatement-pinned"); the reference's own known answers are asserted separately
+in tests/test_oracle_known_answers.py.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz, *.json
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes  # noqa: E402
+
+rtx = importlib.import_module("rust-raytracer_amd")
+orc = importlib.import_module("oracle.oracle")
+
+DET = dict(reflect_depth=4, refract_depth=4, shadow_samples=1, gloss_samples=1, pixel_samples=1, rng_mode=0)
+STO = dict(reflect_depth=3, refract_depth=3, shadow_samples=4, gloss_samples=2, pixel_samples=2, rng_mode=1, seed=7)
+
+# name -> (scene factory, kwargs, size, options)
+CASES = {
+    "sphere_det": (scenes.sphere_scene, {}, (64, 64), DET),
+    "cornell_det": (scenes.cornell_scene, {}, (128, 128), DET),
+    "mesh_det": (scenes.mesh_scene, {}, (128, 96), DET),
+    "mesh_transmissive_det": (scenes.mesh_scene, dict(transmissive=True, point_light=True), (96, 64), DET),
+    "cube_det": (scenes.cube_obj_scene, {}, (64, 64), DET),
+    "cornell_glossy_philox": (scenes.cornell_scene, dict(glossy=True), (64, 64), STO),
+    "mesh_soft16_philox": (scenes.mesh_scene, {}, (96, 64),
+                           dict(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=2, rng_mode=1, seed=3)),
+}
+
+
+def main():
+    for name, (factory, kw, size, opt_kw) in CASES.items():
+        flat, cam_fn = factory(rtx, **kw)
+        cam = cam_fn(*size)
+        rgba, ids, cn = orc.Scene(flat).render(cam, rtx.options(**opt_kw), threads=8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=rgba, ids=ids,
+                            rays=np.array(list(cn.rays), dtype=np.uint64))
+        print(name, size, "rays", list(cn.rays))
+    # ray-level vectors: closest hit ids / t (hex floats) and shadow products on the mesh scene
+    flat, cam_fn = scenes.mesh_scene(rtx)
+    rng = np.random.RandomState(11)
+    cam = cam_fn(64, 64)
+    o, d = [], []
+    for _ in range(256):
+        r = orc.camera_get_ray(cam, rng.uniform(0, 63), rng.uniform(0, 63))
+        o.append(r["origin"]); d.append(r["direction"])
+    o, d = np.array(o), np.array(d)
+    osc = orc.Scene(flat)
+    pid, t, hit = osc.nearest_hits(o, d, want_hit=True)
+    keep = pid >= 0
+    light = np.array(list(flat.lights[0].position))
+    sh = osc.shadow_products(hit[keep, 6:9], np.broadcast_to(light, hit[keep, 6:9].shape).copy())
+    vec = {"origin": [[float.hex(float(x)) for x in row] for row in o],
+           "direction": [[float.hex(float(x)) for x in row] for row in d],
+           "prim_id": pid.tolist(), "t": [float.hex(float(x)) for x in t],
+           "shadow_origin": [[float.hex(float(x)) for x in row] for row in hit[keep, 6:9]],
+           "shadow_target": [float.hex(float(x)) for x in light],
+           "shadow_product": [[float.hex(float(x)) for x in row] for row in sh]}
+    with open(os.path.join(HERE, "mesh_rays.json"), "w") as fh:
+        json.dump(vec, fh)
+    print("mesh_rays.json", len(pid), "rays,", int(keep.sum()), "shadow feelers")
+
+
+if __name__ == "__main__":
+    main()

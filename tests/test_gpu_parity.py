@@ -221,3 +221,67 @@ def test_bad_arguments(rtx):
     with pytest.raises(rtx.abi.RtxError):
         sc.render(cam_fn(32, 32), rtx.options(shard_index=2, shard_count=2))
     sc.close()
+
+
+@pytest.mark.parametrize("tries", [1, 2, 4, 16, 3])
+def test_cooperative_shadows_equal_per_lane_shadows(rtx, tries):
+    """The cooperative 16-lane box-list traversal and the per-lane octree walk are two exact any-hit
+    searches over the same primitives: for every group size (also a non-power-of-two sample count)
+    the images must be identical."""
+    flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32)
+    cam = cam_fn(160, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=3, refract_depth=3, shadow_samples=tries, pixel_samples=2, rng_mode=1, seed=5)
+    a, ia, sa = sc.render(cam, rtx.options(**kw))
+    b, ib, sb = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_NO_COOP, **kw))
+    sc.close()
+    assert np.array_equal(ia, ib)
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all()      # identical up to the order of f64 atomic adds
+    assert (a != b).mean() < 1e-3
+    assert sa.rays_total == sb.rays_total
+
+
+@pytest.mark.parametrize("name,fov,opt", [
+    ("bunny", 45.0, dict(reflect_depth=4, refract_depth=4, shadow_samples=1, pixel_samples=2)),
+    ("sponza", 67.5, dict(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=1)),
+    ("sibenik", 45.0, dict(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=1)),
+])
+def test_baseline_scenes_full_size_properties(rtx, orc, name, fov, opt):
+    """BASELINE.json's scenes at 1920x1080 with their full-size stand-in meshes.  The oracle takes
+    minutes per frame here, so parity is checked (a) against the oracle on two 8-row tile blocks and
+    (b) through size-independent properties: the two independent shadow traversals agree on the
+    whole frame, and interleaved shards reassemble the unsharded frame."""
+    named = rtx.host.NamedScene(name)
+    cam = named.camera(1920, 1080, fov)
+    sc = rtx.Scene(named)
+    kw = dict(rng_mode=1, seed=0, **opt)
+    full, ids, st = sc.render(cam, rtx.options(**kw))
+    alt, ids2, _ = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_NO_COOP, **kw))
+    assert np.array_equal(ids, ids2)
+    assert (np.abs(full.astype(int) - alt.astype(int)) <= 1).all() and (full != alt).mean() < 1e-3
+    out = np.zeros_like(full)
+    for k in range(2):
+        sc.render(cam, rtx.options(shard_index=k, shard_count=2, **kw), want_ids=False, out=out)
+    sc.close()
+    assert (np.abs(out.astype(int) - full.astype(int)) <= 1).all() and (out != full).mean() < 1e-3
+    osc = orc.Scene(named)
+    for b in (40, 100):
+        o_rgba, o_ids, _ = osc.render(cam, rtx.options(**kw), threads=16, rows=(b * 8, b * 8 + 8))
+        rows = slice(b * 8, b * 8 + 8)
+        assert (ids[rows] == o_ids[rows]).mean() >= 0.9999
+        assert (np.abs(full[rows, :, :3].astype(int) - o_rgba[rows, :, :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
+
+
+def test_heptoroid_refractive_deep_recursion(rtx, orc):
+    """BASELINE config 4's material (k_sg = k_tg = 1, transmission 0.8): the branching ray tree and the
+    multiset shadow product against the oracle.  The tree grows ~2x per level, so the oracle-checked
+    case uses depth 7/7 at reduced size; depth 16/16 is exercised by bench.py --workload heptoroid."""
+    named = rtx.host.NamedScene("heptoroid-refractive", detail=0.25)
+    cam = named.camera(96, 64, 45.0)
+    opt = rtx.options(reflect_depth=7, refract_depth=7, shadow_samples=1, pixel_samples=1, rng_mode=0)
+    orgba, oids, ocn = orc.Scene(named).render(cam, opt, threads=16)
+    sc = rtx.Scene(named)
+    rgba, ids, st = sc.render(cam, opt)
+    sc.close()
+    _compare(rgba, ids, orgba, oids)
+    assert st.rays_refract > 10000 and abs(int(st.rays_total) - int(ocn.rays_total)) <= 1e-3 * ocn.rays_total

@@ -1,0 +1,139 @@
+"""CPU-only checks of the C++ host mirror (librtx_host.so): the reference's own unit tests for the
+pieces either side of the trace path, re-expressed against the mirror.  Fixture files
+tests/golden/cube.obj and png24.png are the reference's test/res data files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def test_obj_loads_correct_number_of_triangles(rtx):
+    """util/import.rs:147-153 test_obj_loads_correct_number_of_triangles"""
+    v, n, uv = rtx.host.from_obj(os.path.join(GOLD, "cube.obj"))
+    assert v.shape == (12, 3, 3)
+    assert np.all(uv == 0.0)                      # no `vt` lines: texinfo all zero (import.rs:94-97)
+    # first face `f 2//1 3//1 4//1`: vertices 2,3,4 and normal 1 for all three corners
+    assert np.array_equal(v[0], [[1, -1, 1], [-1, -1, 1], [-1, -1, -1]])
+    assert np.array_equal(n[0], [[0, -1, 0]] * 3)
+
+
+def test_obj_flip_normals_and_transform(rtx):
+    """from_obj(flip_normals = true) negates normals (import.rs:99-103); Mesh::mut_transform
+    (mesh.rs:10-14 -> triangle.rs:158-174) moves vertices by the matrix."""
+    v, n, _ = rtx.host.from_obj(os.path.join(GOLD, "cube.obj"))
+    vf, nf, _ = rtx.host.from_obj(os.path.join(GOLD, "cube.obj"), flip_normals=True)
+    assert np.array_equal(vf, v) and np.array_equal(nf, -n)
+    t = np.eye(4)
+    t[:3, 3] = [10.0, 20.0, 30.0]
+    vt, nt, _ = rtx.host.from_obj(os.path.join(GOLD, "cube.obj"), transform=t)
+    assert np.allclose(vt, v + [10.0, 20.0, 30.0])
+    assert np.allclose(nt, n)                     # a translation leaves normals alone
+
+
+def test_obj_missing_file_is_an_error(rtx):
+    with pytest.raises(IOError):
+        rtx.host.from_obj(os.path.join(GOLD, "no_such.obj"))
+
+
+def test_from_png24(rtx):
+    """util/import.rs:155-180 test_from_png24 (row 0, as the reference asserts)"""
+    img = rtx.host.from_image(os.path.join(GOLD, "png24.png"))
+    assert img.shape == (2, 10, 4)
+    assert np.array_equal(img[0], [[i, i, i, 255] for i in range(10)])
+    # the reference's table also lists a second row, but its loop stops at y = 0 (import.rs:174) and the
+    # file's real row 1 differs from that table; the whole image is pinned against PIL's decoder instead
+    from PIL import Image
+    assert np.array_equal(img, np.asarray(Image.open(os.path.join(GOLD, "png24.png")).convert("RGBA")))
+
+
+def test_to_ppm_bytes(rtx, tmp_path):
+    """util/export.rs:5-18: "P3 W H 255\\n" then "r g b " per pixel, row 0 first, alpha dropped."""
+    img = np.array([[[1, 2, 3, 255], [40, 50, 60, 0]], [[255, 0, 7, 9], [0, 0, 0, 255]]], dtype=np.uint8)
+    path = str(tmp_path / "out.ppm")
+    rtx.host.to_ppm(img, path)
+    assert open(path, "rb").read() == b"P3 2 2 255\n1 2 3 40 50 60 255 0 7 0 0 0 "
+
+
+def test_mat4_inverse(rtx):
+    """mat4.rs:536-555 test_inverse (exact)"""
+    assert np.array_equal(rtx.host.mat4_inverse(np.eye(4)), np.eye(4))
+    m = [[1, 0, 1, 1], [2, 0, 1, 0], [2, 1, 1, 0], [0, 0, 1, 3]]
+    want = [[-3, 2, 0, 1], [0, -1, 1, 0], [6, -3, 0, -2], [-2, 1, 0, 1]]
+    assert np.array_equal(rtx.host.mat4_inverse(m), want)
+
+
+def test_mat4_mult_p_translates_points(rtx):
+    t = np.eye(4)
+    t[:3, 3] = [1.0, 2.0, 3.0]
+    assert np.array_equal(rtx.host.mat4_mult_p(t, [1.0, 1.0, 1.0]), [2.0, 3.0, 4.0])
+
+
+def test_easing(rtx):
+    """animator/easing.rs:45-54 test_easing (linear easing is a Bezier with control points 0, 1/3, 2/3, 1)"""
+    for t in (0.0, 0.25, 0.5, 0.75, 1.0):
+        assert rtx.host.easing_t(t) == t
+
+
+def test_lerp_camera_position(rtx):
+    """animator/animator.rs:121-159 test_lerp_camera_position"""
+    base = rtx.camera((-1, -1, -1), (0, 1, 0), (0, 1, 0), 45.0, 10, 10)
+    keys = [[5.0, 0, 0, 0, 0, 1, 0, 0, 1, 0], [10.0, 10, 0, 0, 0, 1, 0, 0, 1, 0]]
+    for time, want in ((0.0, (-1, -1, -1)), (5.0, (0, 0, 0)), (7.5, (5, 0, 0)), (10.0, (10, 0, 0))):
+        assert tuple(rtx.host.lerp_camera(base, keys, time).position) == tuple(float(x) for x in want)
+
+
+SAMPLE_CONFIG = {   # the reference's sample-config.json, verbatim values (main.rs:34-49 schema)
+    "name": "cornell", "size": [512, 512], "fov": 30.0, "reflect_depth": 3, "refract_depth": 6, "shadow_samples": 64,
+    "gloss_samples": 8, "pixel_samples": 2, "output_file": "test", "animating": False, "fps": 25.0,
+    "time_slice": [0.0, 10.0], "starting_frame_number": 0}
+
+
+def test_parse_sample_config(rtx):
+    cfg = rtx.host.parse_config(json.dumps(SAMPLE_CONFIG))
+    assert cfg["name"] == "cornell" and cfg["size"] == (512, 512) and cfg["fov"] == 30.0
+    assert (cfg["reflect_depth"], cfg["refract_depth"], cfg["shadow_samples"], cfg["gloss_samples"], cfg["pixel_samples"]) == (3, 6, 64, 8, 2)
+    assert cfg["fps"] == 25.0 and cfg["time_slice"] == (0.0, 10.0) and cfg["starting_frame_number"] == 0
+
+
+@pytest.mark.parametrize("missing", sorted(SAMPLE_CONFIG))
+def test_every_config_field_is_mandatory(rtx, missing):
+    """rustc_serialize decodes all 13 fields; a missing one is an error (main.rs:87-101)."""
+    d = dict(SAMPLE_CONFIG)
+    del d[missing]
+    with pytest.raises(ValueError) as e:
+        rtx.host.parse_config(json.dumps(d))
+    assert missing in str(e.value)
+
+
+def test_scene_registry(rtx):
+    """my_scene/mod.rs:27-45: known names resolve, unknown ones do not."""
+    s = rtx.host.NamedScene("cornell")
+    assert s.n_prims == 10 and s.desc.n_planes == 5 and s.desc.n_spheres == 4 and s.desc.n_triangles == 1
+    cam = s.camera(512, 512, 30.0)
+    assert tuple(cam.position) == (50.0, 25.0, 150.0) and tuple(cam.look_at) == (50.0, 50.0, 50.0)   # cornell.rs:16-25
+    with pytest.raises(KeyError):
+        rtx.host.NamedScene("box")               # tools/conf/box.json names a scene the registry no longer has
+
+
+@pytest.mark.parametrize("name,tris,lights", [("sphere", 0, 1), ("bunny", 69938, 2), ("sponza", 262144, 2),
+                                              ("heptoroid-refractive", 114688, 1), ("sibenik", 74880, 3)])
+def test_baseline_scene_sizes(rtx, name, tris, lights):
+    """BASELINE.json's five configs: stand-in meshes have the stated triangle counts; light lists as in
+    the reference's scene files (sphere.rs:83, bunny.rs:27-30, sponza.rs:28-31, heptoroid.rs:27-29, sibenik.rs:49-53)."""
+    s = rtx.host.NamedScene(name)
+    assert s.n_triangles == tris
+    assert len(s.lights) == lights
+
+
+def test_sibenik_animation_camera(rtx):
+    """sibenik.rs:28-46: one keyframe at 7 s; lerp_camera at t=0 is the still camera, at t=7 the keyframe."""
+    s = rtx.host.NamedScene("sibenik", detail=0.1)
+    c0, c7 = s.camera(64, 64, 45.0, time=0.0), s.camera(64, 64, 45.0, time=7.0)
+    assert tuple(c0.position) == (-16.0, -14.5, -2.0)
+    assert np.allclose(tuple(c7.position), (8.0, -13.5, 0.2)) and np.allclose(tuple(c7.up), (-0.9, 0.0, -0.7))
+    mid = s.camera(64, 64, 45.0, time=3.5)
+    assert np.allclose(tuple(mid.position), (-4.0, -14.0, -0.9))

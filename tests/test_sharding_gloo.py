@@ -1,0 +1,88 @@
+"""The N > 1 path on CPU: two `gloo` ranks run the product's gather code (sharding.py) on synthetic
+per-rank frames.  On the GPU box the same code runs over RCCL with rtx_render_device filling the
+rows (bench.py --gpus N)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pattern(W, H):
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    return np.stack([(xx * 7 + yy * 3) % 256, (xx + yy * 11) % 256, (xx * yy) % 256, np.full_like(xx, 255)], axis=-1).astype(np.uint8)
+
+
+def _worker(rank, world, port, W, H, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module("rust-raytracer_amd.sharding")
+    full = torch.from_numpy(_pattern(W, H))
+    # this rank "renders" only the 8-row blocks it owns (what rtx_options.shard_index/count does)
+    mine = torch.zeros_like(full)
+    for b in sh.blocks_of_rank(H, rank, world):
+        mine[b * 8:(b + 1) * 8] = full[b * 8:(b + 1) * 8]
+    g = sh.StillGather(W, H, rank, world, torch.device("cpu"))
+    out = g.gather(mine, dist)
+    ok_still = bool(torch.equal(out, full)) if rank == 0 else out is None
+    # animation: 5 frames over 2 ranks, rounds of `world` frames
+    total = 5
+    got = {}
+    rounds = (total + world - 1) // world
+    for rd in range(rounds):
+        k = rd * world + rank
+        have = k < total
+        frame = torch.full((H, W, 4), k % 251 if have else 0, dtype=torch.uint8)
+        parts = sh.gather_frames(frame, have, rank, world, dist)
+        if rank == 0:
+            for r, p in enumerate(parts):
+                if p is not None:
+                    got[rd * world + r] = int(p[0, 0, 0])
+    ok_anim = (got == {k: k % 251 for k in range(total)}) if rank == 0 else True
+    assert sh.frames_of_rank(total, rank, world) == list(range(rank, total, world))
+    q.put((rank, ok_still, ok_anim))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H", [(96, 64), (50, 136)])
+def test_two_rank_gather(W, H):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1]
+    assert all(r[1] and r[2] for r in results), results
+
+
+def test_block_ownership_partitions_the_frame(rtx):
+    sh = rtx.sharding
+    for H in (8, 64, 1080):
+        for world in (1, 2, 3, 8):
+            owned = sorted(b for r in range(world) for b in sh.blocks_of_rank(H, r, world))
+            assert owned == list(range(H // 8))
+    assert sh.frames_of_rank(175, 3, 8) == list(range(3, 175, 8))     # sibenik: 175 frames over 8 GPUs

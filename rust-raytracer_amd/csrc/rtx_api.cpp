@@ -681,11 +681,10 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         int32_t r = ref_of_prim[(size_t)i];
         pboxes[(size_t)i].ref = r >= 0 ? (RTX_WREF_TRI | (uint32_t)r) : (RTX_WREF_SPHERE | (uint32_t)(~r));
     }
-    std::vector<DBoxList> wide;
+    std::vector<DWideChild> wide;
     RtxWideStats wstats;
     rtx_build_wide_bvh(pboxes, centre, wide, &wstats);
-    // the group stack of k_shadow_coop holds at most 15 pushes per level
-    const bool wide_ok = wstats.depth * (RTX_WIDE - 1) + 1 <= 128 && wide.size() < (1u << 26);
+    const bool wide_ok = 2 * wstats.depth + 2 <= 32 && wstats.nodes < (1 << 26);   // k_shadow_coop's level stack, queue entry bits
     // images -> one RGBA8 atlas
     std::vector<DImage> images((size_t)d->n_images);
     std::vector<uint8_t> atlas;
@@ -737,7 +736,7 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     info.n_leaf_entries = (int64_t)leaf_refs.size();
     info.max_leaf_entries = max_entries;
     info.all_opaque = ds.all_opaque;
-    info.wide_nodes = ds.wide ? (int32_t)wide.size() : 0;
+    info.wide_nodes = ds.wide ? (int32_t)wstats.nodes : 0;
     info.wide_depth = wstats.depth;
     for (int a = 0; a < 3; ++a) { info.root_min[a] = nodes[0].bmin[a]; info.root_max[a] = nodes[0].bmax[a]; }
     *out = s.release();

@@ -159,31 +159,32 @@ struct Builder {
 
 } // namespace
 
-void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DBoxList> &out,
+void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
                         RtxWideStats *stats) {
     out.clear();
-    auto empty_node = []() {
-        DBoxList n;
-        for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < RTX_WIDE; ++c) { n.lo[a][c] = INFINITY; n.hi[a][c] = -INFINITY; }
-        for (int c = 0; c < RTX_WIDE; ++c) n.ref[c] = RTX_WREF_EMPTY;
-        return n;
+    auto add_node = [&]() {   // appends RTX_WIDE empty children, returns the node index
+        DWideChild c;
+        for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
+        c.ref = RTX_WREF_EMPTY;
+        c.first_node = 0;
+        uint32_t idx = (uint32_t)(out.size() / RTX_WIDE);
+        out.insert(out.end(), RTX_WIDE, c);
+        return idx;
     };
     if (stats) *stats = RtxWideStats();
     if (prims.empty()) {
-        out.push_back(empty_node());
+        add_node();
+        if (stats) { stats->nodes = 1; stats->depth = 1; }
         return;
     }
     Builder b(prims);
     int broot = b.build(0, (int)prims.size());
     const std::vector<BNode> &bn = b.nodes;
 
-    struct Task { int wide, bnode; };
+    struct Task { uint32_t wide; int bnode; int depth; };
     std::vector<Task> stack;
-    out.push_back(empty_node());
-    stack.push_back({0, broot});
+    stack.push_back({add_node(), broot, 1});
     int max_depth = 0;
-    std::vector<int> depth_of(1, 1);
     while (!stack.empty()) {
         Task t = stack.back();
         stack.pop_back();
@@ -206,8 +207,10 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
             kids[(size_t)pick] = bn[(size_t)k].left;
             kids.push_back(bn[(size_t)k].right);
         }
-        int d = depth_of[(size_t)t.wide];
-        max_depth = std::max(max_depth, d);
+        max_depth = std::max(max_depth, t.depth);
+        // node-kind children get CONSECUTIVE node indices in slot order (see DWideChild)
+        uint32_t first_node = 0;
+        bool have_first = false;
         for (size_t i = 0; i < kids.size(); ++i) {
             const BNode &k = bn[(size_t)kids[i]];
             uint32_t ref;
@@ -215,21 +218,22 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
                 ref = prims[(size_t)k.prim].ref;
                 if (stats) ++stats->prim_children;
             } else {
-                ref = RTX_WREF_NODE | (uint32_t)out.size();
-                out.push_back(empty_node());
-                depth_of.push_back(d + 1);
-                stack.push_back({(int)(ref & RTX_WREF_INDEX), kids[i]});
+                uint32_t idx = add_node();
+                if (!have_first) { first_node = idx; have_first = true; }
+                ref = RTX_WREF_NODE | idx;
+                stack.push_back({idx, kids[i], t.depth + 1});
             }
-            DBoxList &w = out[(size_t)t.wide];
+            DWideChild &w = out[(size_t)t.wide * RTX_WIDE + i];
             for (int a = 0; a < 3; ++a) {
-                w.lo[a][i] = f32_down(k.mn[a] - centre[a]);
-                w.hi[a][i] = f32_up(k.mx[a] - centre[a]);
+                w.lo[a] = f32_down(k.mn[a] - centre[a]);
+                w.hi[a] = f32_up(k.mx[a] - centre[a]);
             }
-            w.ref[i] = ref;
+            w.ref = ref;
         }
+        for (int i = 0; i < RTX_WIDE; ++i) out[(size_t)t.wide * RTX_WIDE + (size_t)i].first_node = first_node;
     }
     if (stats) {
-        stats->nodes = (int64_t)out.size();
+        stats->nodes = (int64_t)(out.size() / RTX_WIDE);
         stats->depth = max_depth;
     }
 }

@@ -15,5 +15,5 @@ struct RtxWideStats {
     int depth = 0;
 };
 // Boxes are stored relative to `centre`, rounded outward to f32.
-void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DBoxList> &out,
+void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
                         RtxWideStats *stats);

@@ -44,8 +44,7 @@ struct alignas(32) DEntry32 {
 };
 
 // A node of the 16-wide box-list hierarchy walked cooperatively by 16 lanes (one child per lane):
-// SoA so that the 16 lanes of a group read 64 contiguous bytes per array.  Boxes are relative to
-// DScene.centre and rounded outward to f32 like DNode32's.
+// boxes are relative to DScene.centre and rounded outward to f32 like DNode32's.
 #define RTX_WIDE 16
 #define RTX_WREF_NODE   0x00000000u
 #define RTX_WREF_TRI    0x40000000u
@@ -53,10 +52,15 @@ struct alignas(32) DEntry32 {
 #define RTX_WREF_EMPTY  0xC0000000u
 #define RTX_WREF_KIND   0xC0000000u
 #define RTX_WREF_INDEX  0x3FFFFFFFu
-struct alignas(64) DBoxList {
-    float lo[3][RTX_WIDE];
-    float hi[3][RTX_WIDE];
-    uint32_t ref[RTX_WIDE];
+// One child of a wide node, 32 B; a node is RTX_WIDE consecutive children (512 B), lane l of a group
+// reads child l with two 16-byte loads.  Children that are nodes have consecutive node indices in
+// slot order: child s is node  first_node + popcount(node-kind slots below s), so every lane can
+// compute the next node from ballots alone, with no cross-lane data movement.
+struct alignas(32) DWideChild {
+    float lo[3];
+    float hi[3];
+    uint32_t ref;          // RTX_WREF_* kind | index (index unused for RTX_WREF_NODE children)
+    uint32_t first_node;   // same value in all RTX_WIDE children of a node
 };
 
 // Intersection record of a triangle: 3 vertices (triangle.rs:90) + ids, 80 B, 16-B aligned.
@@ -94,7 +98,7 @@ struct DScene {
     const DNode32 *nodes32;
     const DEntry32 *entries32;  // same order as leaf_refs
     const int32_t *leaf_refs;   // >= 0: triangle index, < 0: ~sphere index
-    const DBoxList *wide;       // 16-wide box lists over the finite prims; node 0 = root
+    const DWideChild *wide;     // 16-wide hierarchy over the finite prims: node n = wide[16 n .. 16 n + 15], node 0 = root
     const DTri *tris;
     const DTriShade *tri_shade;
     const DSphere *spheres;

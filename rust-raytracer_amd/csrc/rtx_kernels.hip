@@ -1157,8 +1157,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
 // renderer.rs:212), so the per-ray answer is the exact any-hit answer.  A beam test is interval
 // arithmetic, hence conservative; an axis on which the group's directions change sign is left
 // unconstrained.
-#define RTX_COOP_STACK 128
-#define RTX_COOP_QUEUE 32
+#define RTX_COOP_STACK 64     // words: 32 spilled levels of 2 words (host checks 2 * depth + 2 <= 32)
+#define RTX_COOP_QUEUE 48     // RTX_COOP_QT - 1 + 2 * 16 at most
 #ifndef RTX_COOP_QT
 #define RTX_COOP_QT 6      // drain the candidate queue once it holds this many primitives
 #endif
@@ -1288,79 +1288,106 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         o2min -= slack; o2max += slack;
     }
     const float umax_w = umax * 1.000001f + (o0max - o0min);
-    volatile uint32_t *stack = s_stack[sub];
+    volatile uint32_t *stack = s_stack[sub];   // spilled levels: 2 words each (first node, kind16 << 16 | pending16)
     volatile uint32_t *queue = s_queue[sub];
     const uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t below = (1u << l16) - 1u;
     bool alive = valid;
     uint32_t a16 = (uint32_t)(__ballot(alive) >> gbase) & 0xFFFFu;
-    uint32_t node = a16 ? 0u : NONE;
-    uint32_t sp = 0, qn = 0;
+    // Group state, replicated in every lane of the group (it is computed from ballots only).
+    // A LEVEL is a visited node with node-children still to visit: (tfirst, tmask) is the innermost
+    // one, older ones are spilled to LDS.  Two nodes are tested per step (nodeA, nodeB).
+    uint32_t nodeA = a16 ? 0u : NONE, nodeB = NONE;
+    uint32_t tfirst = 0u, tmask = 0u, sp = 0u, qn = 0u;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
 
+    // beam-vs-box test of one child record (see the comment above the beam set-up)
+    auto keep_box = [&](const float4 &qa, const float4 &qb) -> bool {
+        const float c0l = a0 == 0 ? qa.x : (a0 == 1 ? qa.y : qa.z), c0h = a0 == 0 ? qa.w : (a0 == 1 ? qb.x : qb.y);
+        const float c1l = a1 == 0 ? qa.x : qa.y, c1h = a1 == 0 ? qa.w : qb.x;
+        const float c2l = a2 == 1 ? qa.y : qa.z, c2h = a2 == 1 ? qb.x : qb.y;
+        float u0 = neg0 ? (o0min - c0h) : (c0l - o0max);      // smallest u at which any ray can be inside
+        float u1 = neg0 ? (o0max - c0l) : (c0h - o0min);      // largest
+        u0 = fmaxf(u0, 0.0f);
+        u1 = fminf(u1, umax_w);
+        const float b1lo = o1min + fminf(u0 * m1L, u1 * m1L), b1hi = o1max + fmaxf(u0 * m1H, u1 * m1H);
+        const float b2lo = o2min + fminf(u0 * m2L, u1 * m2L), b2hi = o2max + fmaxf(u0 * m2H, u1 * m2H);
+        return (u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l) || !beam_ok;
+    };
+    // the next node of the group's depth-first walk (NONE when the walk is over)
+    auto take_node = [&]() -> uint32_t {
+        if ((tmask & 0xFFFFu) == 0u && sp > 0u) {   // innermost level exhausted: back to the spilled one (never empty)
+            --sp;
+            tfirst = stack[2u * sp];
+            tmask = stack[2u * sp + 1u];
+        }
+        const uint32_t pend = tmask & 0xFFFFu;
+        if (pend == 0u) return NONE;
+        const uint32_t slot = (uint32_t)__ffs((int)pend) - 1u;
+        tmask &= ~(1u << slot);
+        return tfirst + (uint32_t)__popc((tmask >> 16) & ((1u << slot) - 1u));
+    };
+
     for (;;) {
-        const bool g_on = node != NONE;
+        const bool g_on = nodeA != NONE;
         if (!__any(g_on)) break;
-        bool hit = false, is_node = false;
         if (g_on) {
-            const DBoxList *nd = sc.wide + node;
-            const uint32_t ref = nd->ref[l16];
-            WORK(++w_nodes;)
-            // u range of the box along a0
-            const float c0l = nd->lo[a0][l16], c0h = nd->hi[a0][l16];
-            const float c1l = nd->lo[a1][l16], c1h = nd->hi[a1][l16];
-            const float c2l = nd->lo[a2][l16], c2h = nd->hi[a2][l16];
-            float u0 = neg0 ? (o0min - c0h) : (c0l - o0max);      // smallest u at which any ray can be inside
-            float u1 = neg0 ? (o0max - c0l) : (c0h - o0min);      // largest
-            u0 = fmaxf(u0, 0.0f);
-            u1 = fminf(u1, umax_w);
-            // beam extent on a1, a2 over [u0, u1]
-            const float b1lo = o1min + fminf(u0 * m1L, u1 * m1L), b1hi = o1max + fmaxf(u0 * m1H, u1 * m1H);
-            const float b2lo = o2min + fminf(u0 * m2L, u1 * m2L), b2hi = o2max + fmaxf(u0 * m2H, u1 * m2H);
-#ifdef RTX_COOP_CHECK
-            const bool keep_beam = (u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l);
-            const bool keep = true;
-#else
-            const bool keep = (u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l) || !beam_ok;
-#endif
-            const uint32_t kind = ref & RTX_WREF_KIND;
-            hit = keep && kind != RTX_WREF_EMPTY;
-            is_node = kind == RTX_WREF_NODE;
-            const uint32_t h16 = (uint32_t)(__ballot(hit) >> gbase) & 0xFFFFu;
-            const uint32_t n16 = (uint32_t)(__ballot(hit && is_node) >> gbase) & 0xFFFFu;
-            const uint32_t p16 = h16 & ~n16;
-            if (sp + __popc(n16) > RTX_COOP_STACK) {
-                counters->overflow = 1u;      // cannot happen for depth * 15 < RTX_COOP_STACK (checked on the host)
-            } else {
-                if (hit && is_node) stack[sp + __popc(n16 & below)] = ref & RTX_WREF_INDEX;
-                sp += __popc(n16);
+            const bool hasB = nodeB != NONE;
+            const float4 *pa = reinterpret_cast<const float4 *>(sc.wide + ((size_t)nodeA * RTX_WIDE + l16));
+            const float4 *pb = reinterpret_cast<const float4 *>(sc.wide + ((size_t)(hasB ? nodeB : nodeA) * RTX_WIDE + l16));
+            const float4 a_lo = pa[0], a_hi = pa[1], b_lo = pb[0], b_hi = pb[1];
+            WORK(w_nodes += hasB ? 2u : 1u;)
+            const uint32_t refA = __float_as_uint(a_hi.z), refB = __float_as_uint(b_hi.z);
+            const uint32_t kindA = refA & RTX_WREF_KIND, kindB = refB & RTX_WREF_KIND;
+            const bool hitA = kindA != RTX_WREF_EMPTY && keep_box(a_lo, a_hi);
+            const bool hitB = hasB && kindB != RTX_WREF_EMPTY && keep_box(b_lo, b_hi);
+            const bool isnA = kindA == RTX_WREF_NODE, isnB = kindB == RTX_WREF_NODE;
+            const uint32_t hA = (uint32_t)(__ballot(hitA) >> gbase) & 0xFFFFu, kA = (uint32_t)(__ballot(isnA) >> gbase) & 0xFFFFu;
+            const uint32_t hB = (uint32_t)(__ballot(hitB) >> gbase) & 0xFFFFu, kB = (uint32_t)(__ballot(isnB) >> gbase) & 0xFFFFu;
+            const uint32_t nA = hA & kA, pA = hA & ~kA, nB = hB & kB, pB = hB & ~kB;
+            // primitives the beam touches: queued for the per-ray tests
+            if (hitA && !isnA) queue[qn + __popc(pA & below)] = (nodeA << 4) | l16;
+            qn += __popc(pA);
+            if (hitB && !isnB) queue[qn + __popc(pB & below)] = (nodeB << 4) | l16;
+            qn += __popc(pB);
+            // node children still to visit: a new innermost level per node (B's first, so that A's subtree is walked first)
+            if (nB) {
+                if (tmask & 0xFFFFu) {
+                    if (l16 == 0u) { stack[2u * sp] = tfirst; stack[2u * sp + 1u] = tmask; }
+                    ++sp;
+                }
+                tfirst = __float_as_uint(b_hi.w);
+                tmask = (kB << 16) | nB;
             }
-#ifdef RTX_COOP_CHECK
-            if (hit && !is_node) queue[qn + __popc(p16 & below)] = (node << 4) | l16 | ((keep_beam || !beam_ok) ? 0u : 0x80000000u);
-#else
-            if (hit && !is_node) queue[qn + __popc(p16 & below)] = (node << 4) | l16;
-#endif
-            qn += __popc(p16);
+            if (nA) {
+                if (tmask & 0xFFFFu) {
+                    if (l16 == 0u) { stack[2u * sp] = tfirst; stack[2u * sp + 1u] = tmask; }
+                    ++sp;
+                }
+                tfirst = __float_as_uint(a_hi.w);
+                tmask = (kA << 16) | nA;
+            }
         }
         // ---- drain the candidate queues: every lane tests the primitive against its OWN ray
-        const bool want_x = g_on && (qn >= RTX_COOP_QT || (sp == 0u && qn > 0u));
+        const bool walk_over = (tmask & 0xFFFFu) == 0u && sp == 0u;
+        const bool want_x = g_on && (qn >= RTX_COOP_QT || (walk_over && qn > 0u));
         if (__any(want_x)) {
             while (__any(qn > 0u)) {
                 if (qn > 0u) {
                     --qn;
-#ifdef RTX_COOP_CHECK
-                    const uint32_t c_raw = queue[qn];
-                    const uint32_t c = c_raw & 0x7FFFFFFFu;
-                    const bool was_alive = alive;
-#else
                     const uint32_t c = queue[qn];
+#ifdef RTX_EXP_COOP_NOX
+                    if (c == 0xFFFFFFFFu)      // timing experiment: no per-ray tests at all (wrong images)
+#elif defined(RTX_EXP_COOP_NOEXACT)
+                    if (alive && c == 0xFFFFFFFFu)
+#else
+                    if (alive)
 #endif
-                    if (alive) {
-                        const DBoxList *nd = sc.wide + (c >> 4);
-                        const uint32_t slot = c & 15u;
-                        const uint32_t ref = nd->ref[slot];
-                        const float lx = nd->lo[0][slot], ly = nd->lo[1][slot], lz = nd->lo[2][slot];
-                        const float ux = nd->hi[0][slot], uy = nd->hi[1][slot], uz = nd->hi[2][slot];
+                    {
+                        const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
+                        const float4 c_lo = pc[0], c_hi = pc[1];
+                        const uint32_t ref = __float_as_uint(c_hi.z);
+                        const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
                         WORK(++w_entries;)
                         const float enx = sx ? lx : ux, efx = sx ? ux : lx;
                         const float eny = sy ? ly : uy, efy = sy ? uy : ly;
@@ -1394,25 +1421,17 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                             }
                         }
                     }
-#ifdef RTX_COOP_CHECK
-                    if (was_alive && !alive && (c_raw & 0x80000000u)) {
-                        const DBoxList *nd = sc.wide + (c >> 4);
-                        const uint32_t slot = c & 15u;
-                        if (atomicAdd(&counters->work[0][0], 1ull) < 4ull)
-                            printf("VIOLATION a0=%d neg0=%d o=(%g %g %g) d=(%g %g %g) dist=%g box=(%g %g %g)-(%g %g %g) o0=[%g %g] o1=[%g %g] o2=[%g %g] m1=[%g %g] m2=[%g %g] umax=%g\n",
-                                   a0, (int)neg0, orx, ory, orz, r.dx, r.dy, r.dz, distance_to_light, nd->lo[0][slot], nd->lo[1][slot], nd->lo[2][slot],
-                                   nd->hi[0][slot], nd->hi[1][slot], nd->hi[2][slot], o0min, o0max, o1min, o1max, o2min, o2max, m1L, m1H, m2L, m2H, umax_w);
-                    }
-#endif
                 }
             }
             a16 = (uint32_t)(__ballot(alive) >> gbase) & 0xFFFFu;
-            if (!a16) sp = 0u;   // every feeler of the group is occluded
+            if (!a16) { sp = 0u; tmask = 0u; }   // every feeler of the group is occluded
         }
-        node = NONE;
-        if (g_on && sp > 0u) {
-            --sp;
-            node = stack[sp];
+        nodeA = NONE;
+        nodeB = NONE;
+        if (g_on) {
+            nodeA = take_node();
+            nodeB = take_node();
+            if (nodeA == NONE) { nodeA = nodeB; nodeB = NONE; }
         }
     }
 

@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--batch-rays", type=int, default=0)
     ap.add_argument("--cpu-blocks", type=int, default=3, help="8-row tile blocks the CPU baseline traces (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--reflect", type=int, default=-1, help="override reflect_depth")
+    ap.add_argument("--refract", type=int, default=-1, help="override refract_depth")
+    ap.add_argument("--no-coop", action="store_true", help="RTX_FLAG_NO_COOP: per-lane octree shadows (A/B)")
     args = ap.parse_args()
 
     import numpy as np
@@ -77,6 +80,8 @@ def main():
     scene_name, W, H, fov, refl, refr, shadow, gloss, ps = WORKLOADS[args.workload]
     W = args.width or W
     H = args.height or H
+    refl = args.reflect if args.reflect >= 0 else refl
+    refr = args.refract if args.refract >= 0 else refr
 
     t0 = time.time()
     named = pkg.host.NamedScene(scene_name, detail=args.detail)
@@ -92,7 +97,8 @@ def main():
 
     opt = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
                       pixel_samples=ps, rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0,
-                      shard_index=rank, shard_count=world, batch_rays=args.batch_rays)
+                      shard_index=rank, shard_count=world, batch_rays=args.batch_rays,
+                      flags=pkg.abi.FLAG_NO_COOP if args.no_coop else 0)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

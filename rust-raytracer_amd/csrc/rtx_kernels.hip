@@ -421,6 +421,36 @@ DEV void traverse_exact(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, st
 // candidate still passes the exact f64 entry-bbox test (octree.rs:170) and the exact primitive
 // test before it counts.  NaNs (0 * inf on axis-parallel rays) drop out of v_max3/v_min3, which
 // only weakens the cull.  Near-to-far order by direction sign is exact for octree siblings.
+// Where the ray enters the cube [centre +- radius] that holds every finite primitive.  The f32
+// frame of the fast traversals is re-based there (o' = o + t_shift * d): a ray that starts far
+// outside the scene (a ground plane seen near the horizon puts hit points 1e6 units away) would
+// otherwise need a delta so large that every box is "hit".  A ray that misses the cube (widened
+// by 1e-6) has no finite candidate at all.  Results are unaffected: only the conservative culling
+// depends on it, the exact tests keep using the original ray.
+struct RootEntry {
+    double t_shift;
+    bool miss;
+};
+DEV RootEntry root_entry(const DScene &sc, const Ray &r, double orx, double ory, double orz) {
+    const double R = sc.radius * 1.000001;
+    double tin = 0.0, tout = inf();
+    bool miss = false;
+    const double oo[3] = {orx, ory, orz}, dd[3] = {r.dx, r.dy, r.dz}, ii[3] = {r.ix, r.iy, r.iz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] != 0.0) {
+            double t1 = (-R - oo[a]) * ii[a], t2 = (R - oo[a]) * ii[a];
+            tin = fmax(tin, fmin(t1, t2));
+            tout = fmin(tout, fmax(t1, t2));
+        } else if (fabs(oo[a]) > R) {
+            miss = true;
+        }
+    }
+    RootEntry e;
+    e.miss = miss || tin > tout;
+    e.t_shift = tin;     // >= 0
+    return e;
+}
 DEV float f32_above(double v) {   // a float >= v (v finite or +inf)
     float f = (float)v;
     return f + fabsf(f) * 1.1920929e-7f;
@@ -451,7 +481,9 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
     // The ray in f32 relative to the root centre: slab distance of plane p = fma(p, i, c) with
     // c = -o*i.  The widening by delta is folded into c: cn (near planes, delta towards the
     // origin side) and cf (far planes, delta away), h = delta * |i|.
-    const double orx = r.ox - sc.centre[0], ory = r.oy - sc.centre[1], orz = r.oz - sc.centre[2];
+    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh
+    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
     const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
     const double delta = big * (1.0 / 1048576.0);
     const bool sx = r.sx, sy = r.sy, sz = r.sz;
@@ -464,12 +496,14 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     const uint32_t flip = r.flip;
     const uint8_t *perm_row = perm + (flip << 8);
-    float bf = f32_above(best_t);   // upper bound of best_t for the f32 culls
+    float bf = f32_above(best_t - tsh);   // upper bound of best_t (shifted) for the f32 culls
     int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
 
     int sp = 0;
     uint32_t cur = 0;
     bool have_cur = true;           // root: never culled (octree.rs:149,177)
+    if (re.miss) done = true;       // the ray misses the cube that holds every finite prim
+    const bool skip_finite = re.miss;
     while (!done) {
         if (!have_cur) {
             while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
@@ -559,7 +593,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
                         if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
                             best_t = t;
                             best_ref = ref;
-                            bf = f32_above(best_t);
+                            bf = f32_above(best_t - tsh);
                         }
                     } else if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
                         best_ref = ref; done = true; break;
@@ -575,7 +609,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
                         if (sphere_hit(c, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                             best_t = t;
                             best_ref = ref;
-                            bf = f32_above(best_t);
+                            bf = f32_above(best_t - tsh);
                         }
                     } else if (sphere_hit(c, radius, r, t_lo, t_hi, &t)) {
                         best_ref = ref; done = true; break;
@@ -586,13 +620,13 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
             // taken with delta the OTHER way (cn on a far plane), i.e. a lower bound of the true exit.
             if (MODE == MODE_CLOSEST && best_ref != REF_NONE) {
                 float exit_lo = fminf(fminf(fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny)), fmaf(pfz, iz, cnz));
-                if (finite_dir && best_t <= (double)exit_lo) done = true;
+                if (finite_dir && best_t - tsh <= (double)exit_lo) done = true;
             }
         }
     }
 
     // infinite prims last, in order (octree.rs:163-165,185-186)
-    if (!(MODE == MODE_ANY && done)) {
+    if (!(MODE == MODE_ANY && done && !skip_finite)) {
         for (int p = 0; p < sc.n_planes; ++p) {
             const DPlane &pl = sc.planes[p];
             double t;
@@ -1221,7 +1255,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     }
 
     // ---- own ray in f32 (as traverse_fast) for the per-lane primitive box tests
-    const double orx = r.ox - sc.centre[0], ory = r.oy - sc.centre[1], orz = r.oz - sc.centre[2];
+    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    const double tsh = re.t_shift;   // f32 frame re-based to where the ray enters the scene's cube
+    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
     const bool sx = r.sx, sy = r.sy, sz = r.sz;
     const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
     float cnx, cfx, cny, cfy, cnz, cfz;
@@ -1233,7 +1269,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         cnx = cx - hx; cfx = cx + hx; cny = cy - hy; cfy = cy + hy; cnz = cz - hz; cfz = cz + hz;
     }
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
-    const float tmax_own = f32_above(distance_to_light);
+    const float tmax_own = f32_above(distance_to_light - tsh);
+    // a feeler that misses the scene's cube (or ends before reaching it) has no finite candidate: it takes no
+    // part in the beam and in the per-ray tests
+    const bool walk = valid && !re.miss && distance_to_light >= tsh;
 
     // ---- the group's beam, as a frustum along its dominant axis a0 (the axis with the largest
     // |direction| that every ray of the group travels in the same sense).  With u = distance along
@@ -1249,7 +1288,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     bool gneg[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float lo = grp_min(valid ? (float)dd[a] : INF), hi = grp_max(valid ? (float)dd[a] : -INF);
+        float lo = grp_min(walk ? (float)dd[a] : INF), hi = grp_max(walk ? (float)dd[a] : -INF);
         dmin[a] = lo > 0.0f ? lo : (hi < 0.0f ? -hi : 0.0f);
         gneg[a] = hi < 0.0f;
     }
@@ -1268,13 +1307,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // (tail of the launch) still test boxes for the group and must agree with it
     const bool neg0 = a0 == 0 ? gneg[0] : (a0 == 1 ? gneg[1] : gneg[2]);
     // u = s0 * (coord - origin), s0 = +-1; origin interval along a0, widened below
-    float o0min = grp_min(valid ? f32_below(o0) : INF), o0max = grp_max(valid ? f32_above(o0) : -INF);
-    float o1min = grp_min(valid ? f32_below(o1) : INF), o1max = grp_max(valid ? f32_above(o1) : -INF);
-    float o2min = grp_min(valid ? f32_below(o2) : INF), o2max = grp_max(valid ? f32_above(o2) : -INF);
+    float o0min = grp_min(walk ? f32_below(o0) : INF), o0max = grp_max(walk ? f32_above(o0) : -INF);
+    float o1min = grp_min(walk ? f32_below(o1) : INF), o1max = grp_max(walk ? f32_above(o1) : -INF);
+    float o2min = grp_min(walk ? f32_below(o2) : INF), o2max = grp_max(walk ? f32_above(o2) : -INF);
     const double inv0 = 1.0 / fabs(d0);
-    float m1L = grp_min(valid ? f32_below(d1 * inv0) : INF), m1H = grp_max(valid ? f32_above(d1 * inv0) : -INF);
-    float m2L = grp_min(valid ? f32_below(d2 * inv0) : INF), m2H = grp_max(valid ? f32_above(d2 * inv0) : -INF);
-    const float umax = grp_max(valid ? f32_above(distance_to_light * fabs(d0)) : 0.0f);
+    float m1L = grp_min(walk ? f32_below(d1 * inv0) : INF), m1H = grp_max(walk ? f32_above(d1 * inv0) : -INF);
+    float m2L = grp_min(walk ? f32_below(d2 * inv0) : INF), m2H = grp_max(walk ? f32_above(d2 * inv0) : -INF);
+    const float umax = grp_max(walk ? f32_above((distance_to_light - tsh) * fabs(d0)) : 0.0f);
     {
         float big = fmaxf(fmaxf(fmaxf(fabsf(o0min), fabsf(o0max)), fmaxf(fabsf(o1min), fabsf(o1max))), fmaxf(fabsf(o2min), fabsf(o2max))) +
                     (float)sc.radius;
@@ -1292,8 +1331,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     volatile uint32_t *queue = s_queue[sub];
     const uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t below = (1u << l16) - 1u;
-    bool alive = valid;
-    uint32_t a16 = (uint32_t)(__ballot(alive) >> gbase) & 0xFFFFu;
+    bool alive = valid;     // the feeler has met no occluder yet
+    bool seek = walk;       // ... and can still meet a finite one
+    uint32_t a16 = (uint32_t)(__ballot(seek) >> gbase) & 0xFFFFu;
     // Group state, replicated in every lane of the group (it is computed from ballots only).
     // A LEVEL is a visited node with node-children still to visit: (tfirst, tmask) is the innermost
     // one, older ones are spilled to LDS.  Two nodes are tested per step (nodeA, nodeB).
@@ -1381,7 +1421,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
 #elif defined(RTX_EXP_COOP_NOEXACT)
                     if (alive && c == 0xFFFFFFFFu)
 #else
-                    if (alive)
+                    if (seek)
 #endif
                     {
                         const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
@@ -1408,7 +1448,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                                 if (surely_in || tri_bbox_hit(tr, r)) {
                                     WORK(++w_prims;)
                                     double t, be, ga;
-                                    if (tri_hit(tr, r, EPSILON, distance_to_light, &t, &be, &ga)) alive = false;
+                                    if (tri_hit(tr, r, EPSILON, distance_to_light, &t, &be, &ga)) { alive = false; seek = false; }
                                 }
                             } else {
                                 const DSphere &sp_ = sc.spheres[idx];
@@ -1416,14 +1456,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                                 if (surely_in || sphere_bbox_hit(cc, sp_.r, r)) {
                                     WORK(++w_prims;)
                                     double t;
-                                    if (sphere_hit(cc, sp_.r, r, EPSILON, distance_to_light, &t)) alive = false;
+                                    if (sphere_hit(cc, sp_.r, r, EPSILON, distance_to_light, &t)) { alive = false; seek = false; }
                                 }
                             }
                         }
                     }
                 }
             }
-            a16 = (uint32_t)(__ballot(alive) >> gbase) & 0xFFFFu;
+            a16 = (uint32_t)(__ballot(seek) >> gbase) & 0xFFFFu;
             if (!a16) { sp = 0u; tmask = 0u; }   // every feeler of the group is occluded
         }
         nodeA = NONE;
@@ -1557,7 +1597,10 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     if (n_groups == 0 || tries == 0) return;
     uint32_t pow2 = (tries <= 64u && (tries & (tries - 1u)) == 0u) ? 1u : 0u;
     uint64_t lanes = (uint64_t)n_groups * tries;
-    if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP))
+    // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
+    // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
+    // wide (a ground plane seen near the horizon) and walk most of the hierarchy
+    if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && tries % 16u == 0u)
         hipLaunchKernelGGL(k_shadow_coop, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, n_groups,
                            tries, pow2, counters, acc);
     else if (sc.all_opaque)

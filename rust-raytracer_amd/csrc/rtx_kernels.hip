@@ -1203,21 +1203,32 @@ DEV float f32_below(double v) {   // a float <= v
     float f = (float)v;
     return f - fabsf(f) * 1.1920929e-7f;
 }
+// min / max over the 16 lanes of a DPP row (= one cooperative group), result in every lane: an xor
+// butterfly made of DPP lane patterns (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror), four VALU instructions and no LDS traffic (a __shfl_xor is a ds_bpermute).
 DEV float grp_min(float v) {
-    v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2));
-    v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 8));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
     return v;
 }
 DEV float grp_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
     return v;
 }
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
                                                                             uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
                                                                             DCounters *counters, double *acc) {
+    // group-shared LDS, written and read by lanes of ONE wave: the LDS executes a wave's operations in
+    // order, COOP_FENCE() keeps the compiler from moving them across each other (a `volatile` array would
+    // turn them into flat, cache-bypassing accesses)
     __shared__ uint32_t s_stack[RTX_BLOCK / 16][RTX_COOP_STACK];
     __shared__ uint32_t s_queue[RTX_BLOCK / 16][RTX_COOP_QUEUE];
+#define COOP_FENCE() asm volatile("" ::: "memory")
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
     bool valid = group < n_groups;
@@ -1326,9 +1337,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         o1min -= slack; o1max += slack;
         o2min -= slack; o2max += slack;
     }
-    const float umax_w = umax * 1.000001f + (o0max - o0min);
-    volatile uint32_t *stack = s_stack[sub];   // spilled levels: 2 words each (first node, kind16 << 16 | pending16)
-    volatile uint32_t *queue = s_queue[sub];
+    float umax_w = umax * 1.000001f + (o0max - o0min);
+    if (!beam_ok) {   // mixed directions: an all-embracing beam keeps every non-empty box (an empty one is (+inf, -inf): NaN, dropped)
+        o0min = o1min = o2min = -INF;
+        o0max = o1max = o2max = INF;
+        m1L = m1H = m2L = m2H = 0.0f;
+        umax_w = 1.0f;
+    }
+#define COOP_STK(i) s_stack[sub][(i)]   /* spilled levels: 2 words each (first node, kind16 << 16 | pending16) */
+#define COOP_QUE(i) s_queue[sub][(i)]
     const uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t below = (1u << l16) - 1u;
     bool alive = valid;     // the feeler has met no occluder yet
@@ -1352,14 +1369,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         u1 = fminf(u1, umax_w);
         const float b1lo = o1min + fminf(u0 * m1L, u1 * m1L), b1hi = o1max + fmaxf(u0 * m1H, u1 * m1H);
         const float b2lo = o2min + fminf(u0 * m2L, u1 * m2L), b2hi = o2max + fmaxf(u0 * m2H, u1 * m2H);
-        return (u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l) || !beam_ok;
+        return u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l;
     };
     // the next node of the group's depth-first walk (NONE when the walk is over)
     auto take_node = [&]() -> uint32_t {
         if ((tmask & 0xFFFFu) == 0u && sp > 0u) {   // innermost level exhausted: back to the spilled one (never empty)
             --sp;
-            tfirst = stack[2u * sp];
-            tmask = stack[2u * sp + 1u];
+            COOP_FENCE();
+            tfirst = COOP_STK(2u * sp);
+            tmask = COOP_STK(2u * sp + 1u);
         }
         const uint32_t pend = tmask & 0xFFFFu;
         if (pend == 0u) return NONE;
@@ -1379,34 +1397,30 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             WORK(w_nodes += hasB ? 2u : 1u;)
             const uint32_t refA = __float_as_uint(a_hi.z), refB = __float_as_uint(b_hi.z);
             const uint32_t kindA = refA & RTX_WREF_KIND, kindB = refB & RTX_WREF_KIND;
-            const bool hitA = kindA != RTX_WREF_EMPTY && keep_box(a_lo, a_hi);
-            const bool hitB = hasB && kindB != RTX_WREF_EMPTY && keep_box(b_lo, b_hi);
+            const bool hitA = keep_box(a_lo, a_hi);             // an empty child's box is (+inf, -inf): never kept
+            const bool hitB = hasB && keep_box(b_lo, b_hi);
             const bool isnA = kindA == RTX_WREF_NODE, isnB = kindB == RTX_WREF_NODE;
             const uint32_t hA = (uint32_t)(__ballot(hitA) >> gbase) & 0xFFFFu, kA = (uint32_t)(__ballot(isnA) >> gbase) & 0xFFFFu;
             const uint32_t hB = (uint32_t)(__ballot(hitB) >> gbase) & 0xFFFFu, kB = (uint32_t)(__ballot(isnB) >> gbase) & 0xFFFFu;
             const uint32_t nA = hA & kA, pA = hA & ~kA, nB = hB & kB, pB = hB & ~kB;
             // primitives the beam touches: queued for the per-ray tests
-            if (hitA && !isnA) queue[qn + __popc(pA & below)] = (nodeA << 4) | l16;
+            if (hitA && !isnA) COOP_QUE(qn + __popc(pA & below)) = (nodeA << 4) | l16;
             qn += __popc(pA);
-            if (hitB && !isnB) queue[qn + __popc(pB & below)] = (nodeB << 4) | l16;
+            if (hitB && !isnB) COOP_QUE(qn + __popc(pB & below)) = (nodeB << 4) | l16;
             qn += __popc(pB);
-            // node children still to visit: a new innermost level per node (B's first, so that A's subtree is walked first)
-            if (nB) {
-                if (tmask & 0xFFFFu) {
-                    if (l16 == 0u) { stack[2u * sp] = tfirst; stack[2u * sp + 1u] = tmask; }
-                    ++sp;
-                }
-                tfirst = __float_as_uint(b_hi.w);
-                tmask = (kB << 16) | nB;
-            }
-            if (nA) {
-                if (tmask & 0xFFFFu) {
-                    if (l16 == 0u) { stack[2u * sp] = tfirst; stack[2u * sp + 1u] = tmask; }
-                    ++sp;
-                }
-                tfirst = __float_as_uint(a_hi.w);
-                tmask = (kA << 16) | nA;
-            }
+            // node children still to visit: a new innermost level per node (B's first, so that A's subtree is
+            // walked first); the level it displaces is spilled if it still has children pending
+            const bool spillB = nB != 0u && (tmask & 0xFFFFu) != 0u;
+            if (spillB && l16 == 0u) { COOP_STK(2u * sp) = tfirst; COOP_STK(2u * sp + 1u) = tmask; }
+            sp += spillB ? 1u : 0u;
+            tfirst = nB ? __float_as_uint(b_hi.w) : tfirst;
+            tmask = nB ? ((kB << 16) | nB) : tmask;
+            const bool spillA = nA != 0u && (tmask & 0xFFFFu) != 0u;
+            if (spillA && l16 == 0u) { COOP_STK(2u * sp) = tfirst; COOP_STK(2u * sp + 1u) = tmask; }
+            sp += spillA ? 1u : 0u;
+            tfirst = nA ? __float_as_uint(a_hi.w) : tfirst;
+            tmask = nA ? ((kA << 16) | nA) : tmask;
+            COOP_FENCE();
         }
         // ---- drain the candidate queues: every lane tests the primitive against its OWN ray
         const bool walk_over = (tmask & 0xFFFFu) == 0u && sp == 0u;
@@ -1415,7 +1429,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             while (__any(qn > 0u)) {
                 if (qn > 0u) {
                     --qn;
-                    const uint32_t c = queue[qn];
+                    COOP_FENCE();
+                    const uint32_t c = COOP_QUE(qn);
 #ifdef RTX_EXP_COOP_NOX
                     if (c == 0xFFFFFFFFu)      // timing experiment: no per-ray tests at all (wrong images)
 #elif defined(RTX_EXP_COOP_NOEXACT)

@@ -941,7 +941,10 @@ DEV uint32_t block_alloc(uint32_t c, uint32_t *counter, uint32_t *s_tmp /* >= 6 
 // ray's own index (no compaction, no atomics; a ray without a hit marks its group empty);
 // reflection / gloss / transmission children -> ray pool; miss -> skybox / background.
 #define SHADOW_GROUP_EMPTY 0xFFFFFFFFu
-__global__ void __launch_bounds__(RTX_BLOCK) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
+#ifndef RTX_SHADE_WAVES
+#define RTX_SHADE_WAVES 2
+#endif
+__global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                      const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
                                                      double *acc, int32_t *prim_id_out) {
     __shared__ uint32_t s_tmp[8];

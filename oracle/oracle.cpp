@@ -127,6 +127,19 @@ struct Rng {
         *a = (double)(ua >> 11) * (1.0 / 9007199254740992.0);
         *b = (double)(ub >> 11) * (1.0 / 9007199254740992.0);
     }
+    // three uniform draws in (0,1) from ONE Philox block, 32 random bits each: (word + 0.5) / 2^32
+    // (exact in f64).  Used where the reference draws three numbers in a row (spherelight.rs:14-19,
+    // vec3.rs:114-116).
+    void draw3(uint64_t key, uint32_t stream, uint32_t i, uint32_t j, double *a, double *b, double *c) const {
+        if (mode == RTX_RNG_CENTER) { *a = 0.5; *b = 0.5; *c = 0.5; return; }
+        uint32_t ctr[4] = {stream, i, j, TAG_DRAW};
+        uint32_t k[2] = {(uint32_t)key, (uint32_t)(key >> 32)};
+        uint32_t o[4];
+        philox4x32_10(ctr, k, o);
+        *a = ((double)o[0] + 0.5) * (1.0 / 4294967296.0);
+        *b = ((double)o[1] + 0.5) * (1.0 / 4294967296.0);
+        *c = ((double)o[2] + 0.5) * (1.0 / 4294967296.0);
+    }
 };
 
 // ---------------------------------------------------------------- counters
@@ -571,9 +584,8 @@ struct Light {
     // pointlight.rs:11-13 / spherelight.rs:13-23 (a CUBE of side `radius`; jitters even for 1 try)
     Vec3 position(const Rng &rng, uint64_t key, uint32_t light_index, uint32_t k) const {
         if (is_point()) return center();
-        double ux, uy, uz, unused;
-        rng.draw2(key, STREAM_LIGHT, light_index, 2 * k, &ux, &uy);
-        rng.draw2(key, STREAM_LIGHT, light_index, 2 * k + 1, &uz, &unused);
+        double ux, uy, uz;
+        rng.draw3(key, STREAM_LIGHT, light_index, k, &ux, &uy, &uz);
         Vec3 jitter = v3(l.radius * (ux - 0.5), l.radius * (uy - 0.5), l.radius * (uz - 0.5));
         return center() + jitter;
     }
@@ -653,9 +665,8 @@ bool get_nearest_hit(const Scene &scene, const Ray &ray, Intersection *nearest_h
 
 // Ray::perturb (ray.rs:68-81) with Vec3::random (vec3.rs:112-126) drawn from the child's key
 Ray ray_perturb(const Ray &r, double magnitude, const Rng &rng, uint64_t key) {
-    double u_phi, u_cos, u_r, unused;
-    rng.draw2(key, STREAM_GLOSS, 0, 0, &u_phi, &u_cos);
-    rng.draw2(key, STREAM_GLOSS, 0, 1, &u_r, &unused);
+    double u_phi, u_cos, u_r;
+    rng.draw3(key, STREAM_GLOSS, 0, 0, &u_phi, &u_cos, &u_r);
     double phi = 0.0 + (2.0 * PI - 0.0) * u_phi;                   // gen_range(0, 2pi)
     double costheta = -1.0 + (1.0 - -1.0) * u_cos;                 // gen_range(-1, 1)
     double u = 0.0 + (1.0 - 0.0) * u_r;                            // gen_range(0, 1)
@@ -1216,6 +1227,10 @@ uint64_t orc_child_key(uint64_t parent, uint32_t code) { return child_key(parent
 void orc_draw2(uint32_t mode, uint64_t key, uint32_t stream, uint32_t i, uint32_t j, double *out2) {
     Rng r{mode};
     r.draw2(key, stream, i, j, &out2[0], &out2[1]);
+}
+void orc_draw3(uint32_t mode, uint64_t key, uint32_t stream, uint32_t i, uint32_t j, double *out3) {
+    Rng r{mode};
+    r.draw3(key, stream, i, j, &out3[0], &out3[1], &out3[2]);
 }
 double orc_epsilon(void) { return EPSILON; }
 

@@ -130,6 +130,7 @@ def lib():
     L.orc_child_key.argtypes = [C.c_uint64, C.c_uint32]
     L.orc_child_key.restype = C.c_uint64
     L.orc_draw2.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp]
+    L.orc_draw3.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp]
     L.orc_epsilon.restype = C.c_double
     _lib = L
     return L
@@ -326,6 +327,12 @@ def child_key(parent, code):
 def draw2(mode, key, stream, i, j):
     out = np.zeros(2)
     lib().orc_draw2(mode, key, stream, i, j, _p(out))
+    return out
+
+
+def draw3(mode, key, stream, i, j):
+    out = np.zeros(3)
+    lib().orc_draw3(mode, key, stream, i, j, _p(out))
     return out
 
 

@@ -99,6 +99,15 @@ DEV void draw2(uint32_t mode, uint64_t key, uint32_t stream, uint32_t i, uint32_
     *a = (double)(ua >> 11) * (1.0 / 9007199254740992.0);
     *b = (double)(ub >> 11) * (1.0 / 9007199254740992.0);
 }
+// three draws from ONE Philox block, (word + 0.5) / 2^32 each: the light and gloss samplers
+DEV void draw3(uint32_t mode, uint64_t key, uint32_t stream, uint32_t i, uint32_t j, double *a, double *b, double *c) {
+    if (mode == RTX_RNG_CENTER) { *a = 0.5; *b = 0.5; *c = 0.5; return; }
+    uint32_t o[4];
+    philox4x32_10(stream, i, j, TAG_DRAW, (uint32_t)key, (uint32_t)(key >> 32), o);
+    *a = ((double)o[0] + 0.5) * (1.0 / 4294967296.0);
+    *b = ((double)o[1] + 0.5) * (1.0 / 4294967296.0);
+    *c = ((double)o[2] + 0.5) * (1.0 / 4294967296.0);
+}
 
 // ------------------------------------------------------------------------------ raytracer/ray.rs:15-42
 struct Ray {
@@ -1092,9 +1101,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
         for (uint32_t g = 0; g < n_reflect; ++g) {
             // Ray::perturb (ray.rs:68-81) with Vec3::random (vec3.rs:112-126)
             uint64_t ck = child_key(key, CODE_GLOSS0 + g);
-            double u_phi, u_cos, u_r, un;
-            draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 0, &u_phi, &u_cos);
-            draw2(fr.rng_mode, ck, STREAM_GLOSS, 0, 1, &u_r, &un);
+            double u_phi, u_cos, u_r;
+            draw3(fr.rng_mode, ck, STREAM_GLOSS, 0, 0, &u_phi, &u_cos, &u_r);
             double phi = 0.0 + (2.0 * PI - 0.0) * u_phi;
             double costheta = -1.0 + (1.0 - -1.0) * u_cos;
             double uu = 0.0 + (1.0 - 0.0) * u_r;
@@ -1155,9 +1163,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
         const rtx_light &lt = sc.lights[light];
         V3 sampled = v3(lt.position[0], lt.position[1], lt.position[2]);
         if (lt.kind != RTX_LIGHT_POINT) {                                                // spherelight.rs:13-23
-            double ux, uy, uz, un;
-            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k, &ux, &uy);
-            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k + 1u, &uz, &un);
+            double ux, uy, uz;
+            draw3(fr.rng_mode, key, STREAM_LIGHT, light, k, &ux, &uy, &uz);
             V3 jitter = v3(lt.radius * (ux - 0.5), lt.radius * (uy - 0.5), lt.radius * (uz - 0.5));
             sampled = sampled + jitter;
         }
@@ -1207,21 +1214,43 @@ DEV float f32_below(double v) {   // a float <= v
     return f - fabsf(f) * 1.1920929e-7f;
 }
 // min / max over the 16 lanes of a DPP row (= one cooperative group), result in every lane: an xor
-// butterfly made of DPP lane patterns (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
-// row_mirror), four VALU instructions and no LDS traffic (a __shfl_xor is a ds_bpermute).
-DEV float grp_min(float v) {
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
-    return v;
+// butterfly of DPP-modified v_min/v_max (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror): four VALU instructions per value and no LDS traffic (a __shfl_xor is a ds_bpermute).
+// Written as asm because fminf() of a DPP move costs three instructions per step (move, canonicalise,
+// min).  A VALU result needs two wait states before a DPP operand reads it: the pair form interleaves
+// two butterflies so that one s_nop per step is enough.  All 64 lanes must be active.
+DEV void grp_min_max(float lo_in, float hi_in, float *lo_out, float *hi_out) {
+    float a, b;
+    asm("s_nop 1\n\t"
+        "v_min_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(a), "=&v"(b)
+        : "v"(lo_in), "v"(hi_in));
+    *lo_out = a;
+    *hi_out = b;
 }
 DEV float grp_max(float v) {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
-    return v;
+    float a;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(a)
+        : "v"(v));
+    return a;
 }
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
                                                                             uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
@@ -1257,9 +1286,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const rtx_light &lt = sc.lights[light];
         V3 sampled = v3(lt.position[0], lt.position[1], lt.position[2]);
         if (lt.kind != RTX_LIGHT_POINT) {                                                // spherelight.rs:13-23
-            double ux, uy, uz, un;
-            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k, &ux, &uy);
-            draw2(fr.rng_mode, key, STREAM_LIGHT, light, 2u * k + 1u, &uz, &un);
+            double ux, uy, uz;
+            draw3(fr.rng_mode, key, STREAM_LIGHT, light, k, &ux, &uy, &uz);
             V3 jitter = v3(lt.radius * (ux - 0.5), lt.radius * (uy - 0.5), lt.radius * (uz - 0.5));
             sampled = sampled + jitter;
         }
@@ -1302,7 +1330,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     bool gneg[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float lo = grp_min(walk ? (float)dd[a] : INF), hi = grp_max(walk ? (float)dd[a] : -INF);
+        float lo, hi;
+        grp_min_max(walk ? (float)dd[a] : INF, walk ? (float)dd[a] : -INF, &lo, &hi);
         dmin[a] = lo > 0.0f ? lo : (hi < 0.0f ? -hi : 0.0f);
         gneg[a] = hi < 0.0f;
     }
@@ -1321,12 +1350,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // (tail of the launch) still test boxes for the group and must agree with it
     const bool neg0 = a0 == 0 ? gneg[0] : (a0 == 1 ? gneg[1] : gneg[2]);
     // u = s0 * (coord - origin), s0 = +-1; origin interval along a0, widened below
-    float o0min = grp_min(walk ? f32_below(o0) : INF), o0max = grp_max(walk ? f32_above(o0) : -INF);
-    float o1min = grp_min(walk ? f32_below(o1) : INF), o1max = grp_max(walk ? f32_above(o1) : -INF);
-    float o2min = grp_min(walk ? f32_below(o2) : INF), o2max = grp_max(walk ? f32_above(o2) : -INF);
+    float o0min, o0max, o1min, o1max, o2min, o2max, m1L, m1H, m2L, m2H;
+    grp_min_max(walk ? f32_below(o0) : INF, walk ? f32_above(o0) : -INF, &o0min, &o0max);
+    grp_min_max(walk ? f32_below(o1) : INF, walk ? f32_above(o1) : -INF, &o1min, &o1max);
+    grp_min_max(walk ? f32_below(o2) : INF, walk ? f32_above(o2) : -INF, &o2min, &o2max);
     const double inv0 = 1.0 / fabs(d0);
-    float m1L = grp_min(walk ? f32_below(d1 * inv0) : INF), m1H = grp_max(walk ? f32_above(d1 * inv0) : -INF);
-    float m2L = grp_min(walk ? f32_below(d2 * inv0) : INF), m2H = grp_max(walk ? f32_above(d2 * inv0) : -INF);
+    grp_min_max(walk ? f32_below(d1 * inv0) : INF, walk ? f32_above(d1 * inv0) : -INF, &m1L, &m1H);
+    grp_min_max(walk ? f32_below(d2 * inv0) : INF, walk ? f32_above(d2 * inv0) : -INF, &m2L, &m2H);
     const float umax = grp_max(walk ? f32_above((distance_to_light - tsh) * fabs(d0)) : 0.0f);
     {
         float big = fmaxf(fmaxf(fmaxf(fabsf(o0min), fabsf(o0max)), fmaxf(fabsf(o1min), fabsf(o1max))), fmaxf(fabsf(o2min), fabsf(o2max))) +
@@ -1618,7 +1648,12 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
     // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
     // wide (a ground plane seen near the horizon) and walk most of the hierarchy
-    if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && tries % 16u == 0u)
+#ifdef RTX_EXP_COOP_ANY_TRIES
+    const bool single_origin = true;     // timing experiment: groups of 16 consecutive feelers whatever their hit points
+#else
+    const bool single_origin = tries % 16u == 0u;
+#endif
+    if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && single_origin)
         hipLaunchKernelGGL(k_shadow_coop, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, n_groups,
                            tries, pow2, counters, acc);
     else if (sc.all_opaque)

@@ -187,3 +187,13 @@ def test_center_mode_draws_are_half(orc):
     assert orc.draw2(0, 123, 1, 2, 3).tolist() == [0.5, 0.5]
     d = orc.draw2(1, 123, 1, 2, 3)
     assert 0.0 <= d[0] < 1.0 and 0.0 <= d[1] < 1.0 and d[0] != d[1]
+    assert orc.draw3(0, 123, 1, 2, 3).tolist() == [0.5, 0.5, 0.5]
+
+
+def test_draw3_is_one_philox_block(orc):
+    """(word + 0.5) / 2^32 of the first three words of philox(ctr = (stream, i, j, 'DRAW'), key)."""
+    key = 0x0123456789ABCDEF
+    words = orc.philox4x32_10([1, 2, 3, 0x44524157], [key & 0xFFFFFFFF, key >> 32])
+    d = orc.draw3(1, key, 1, 2, 3)
+    assert d.tolist() == [(int(w) + 0.5) / 4294967296.0 for w in words[:3]]
+    assert all(0.0 < x < 1.0 for x in d)

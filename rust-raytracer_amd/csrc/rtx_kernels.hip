@@ -1265,7 +1265,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
     bool valid = group < n_groups;
     size_t qc = sq.cap;
-    V3 hp = v3(0, 0, 0), w = v3(0, 0, 0);
+    V3 hp = v3(0, 0, 0);
     uint64_t key = 0;
     uint32_t sample = 0;
     if (valid) {
@@ -1275,7 +1275,6 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     if (valid) {
         const double *f = sq.f + (size_t)light * 6 * qc + group;
         hp = v3(f[0 * qc], f[1 * qc], f[2 * qc]);
-        w = v3(f[3 * qc], f[4 * qc], f[5 * qc]);
         key = sq.key[(size_t)light * qc + group];
     }
 
@@ -1539,15 +1538,20 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
 #endif
     V3 v = (valid && alive) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
     double inv_tries = 1.0 / (double)tries;
+    // the group's weight (light colour x material sample x path throughput) is fetched only now, by the lanes
+    // that add to the accumulator: held in registers across the walk it would be spilled to scratch memory
     if (pow2_tries) {
         for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
             v.x += __shfl_xor(v.x, (int)off);
             v.y += __shfl_xor(v.y, (int)off);
             v.z += __shfl_xor(v.z, (int)off);
         }
-        if (valid && k == 0u) acc_add(acc, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
-    } else if (valid) {
-        acc_add(acc, sample, w * scale(v, inv_tries));
+    }
+    if (valid && (k == 0u || !pow2_tries)) {
+        uint32_t g2 = group;
+        asm volatile("" : "+v"(g2));   // fresh loads, not the prologue's values kept alive
+        const double *f = sq.f + (size_t)light * 6 * qc + g2;
+        acc_add(acc, sq.sample[(size_t)light * qc + g2], v3(f[3 * qc], f[4 * qc], f[5 * qc]) * scale(v, inv_tries));   // renderer.rs:220,118
     }
 }
 

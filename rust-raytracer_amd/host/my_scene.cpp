@@ -1,5 +1,5 @@
-// my_scene.cpp — the scene registry (src/my_scene/mod.rs:27-45) with the constants of the
-// five BASELINE scenes + cornell transcribed as data.
+// my_scene.cpp — the scene registry (src/my_scene/mod.rs:27-45): all 14 names of the reference, constants
+// transcribed as data.
 //
 // The reference's model and skybox assets (docs/assets git submodule) are NOT in this
 // pipeline.  Each scene first tries the reference's own file paths under `asset_root`
@@ -128,12 +128,22 @@ std::shared_ptr<const CubeMap> skybox_or_standin(const std::string &root, const 
     int size = scaled(512, detail);
     return procedural_skybox(size < 8 ? 8 : size, 1);
 }
-bool obj_or_nothing(const Material &m, const std::string &root, const char *file, std::vector<Prim> &prims) {
+bool obj_or_nothing(const Material &m, const std::string &root, const char *file, std::vector<Prim> &prims, bool flip_normals = false,
+                    const Transform *xf = nullptr) {
     Mesh mesh;
     std::string err;
-    if (!util::from_obj(m, false, root + "/docs/assets/models/" + file, &mesh, &err)) return false;
+    if (!util::from_obj(m, flip_normals, root + "/docs/assets/models/" + file, &mesh, &err)) return false;
+    if (xf) mesh.mut_transform(*xf);
     for (auto &t : mesh.triangles) prims.push_back(std::move(t));
     return true;
+}
+// A stand-in mesh goes through the same Mesh::mut_transform (mesh.rs:10-14) the reference applies to the loaded OBJ.
+void add_grid_transformed(std::vector<Prim> &out, const MaterialPtr &mat, const SurfFn &f, int nu, int nv, const Transform &xf,
+                          bool skip_pole0 = false, bool skip_pole1 = false) {
+    Mesh mesh;
+    add_grid(mesh.triangles, mat, f, nu, nv, skip_pole0, skip_pole1);
+    mesh.mut_transform(xf);
+    for (auto &t : mesh.triangles) out.push_back(std::move(t));
 }
 Material ct(double k_a, double k_d, double k_s, double k_sg, double k_tg, double gauss, double rough, double gloss, double ior,
             Vec3 ambient, Vec3 diffuse, Vec3 specular, Vec3 transmission, TexturePtr tex = nullptr) {
@@ -399,20 +409,167 @@ struct CornellConfig : Base {
     }
 };
 
+// ---------------------------------------------------------------------- my_scene/cow.rs
+struct CowConfig : Base {
+    using Base::Base;
+    Camera get_camera(uint32_t w, uint32_t h, double fov) const override {                // cow.rs:15-24
+        return Camera::create({-2, 4, 10}, {0, 0, 0}, {0, 1, 0}, fov, w, h);
+    }
+    std::shared_ptr<Scene> get_scene() const override {                                    // cow.rs:26-48
+        auto s = std::make_shared<Scene>();
+        s->lights.push_back(SphereLight({3, 10, 6}, Vec3::one(), 5.0));
+        Material red = ct(0.0, 0.6, 1.0, 0.2, 0.0, 30.0, 0.1, 0.0, 0.8, Vec3::one(), {1.0, 0.25, 0.1}, Vec3::one(), Vec3::zero());
+        Material green = ct(0.0, 0.5, 0.4, 0.1, 0.0, 25.0, 0.4, 0.0, 0.95, Vec3::one(), {0.2, 0.7, 0.2}, Vec3::one(), Vec3::zero());
+        s->prims.push_back(Plane(0.0, 1.0, 0.0, 3.6, boxed(green)));
+        if (!obj_or_nothing(red, root, "cow.obj", s->prims, true)) {
+            // stand-in ("5000 polys", cow.rs:14): an elongated blob standing on the y = -3.6 plane, 2*50*50 triangles
+            add_grid(s->prims, boxed(red), blob({0, -0.6, 0}, 3.0, 0.18, 1.3, {1.5, 1.0, 0.8}), scaled(50, detail), scaled(50, detail));
+        }
+        s->background = {0.3, 0.5, 0.8};
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------------- my_scene/easing.rs
+struct EasingConfig : Base {
+    using Base::Base;
+    Camera get_camera(uint32_t w, uint32_t h, double fov) const override {                // easing.rs:18-27
+        return Camera::create({0, 0, 150}, {0, 0, 0}, {0, 1, 0}, fov, w, h);
+    }
+    Camera get_animation_camera(uint32_t w, uint32_t h, double fov) const override {      // easing.rs:29-47
+        return Camera::new_with_keyframes({0, 0, 150}, {0, 0, 0}, {0, 1, 0}, fov, w, h,
+                                          {{10.0, {0, 1000, 150}, {0, 1000, 0}, {0, 1, 0}, Easing{0.0, 0.05, 0.1, 1.0}}});
+    }
+    std::shared_ptr<Scene> get_scene() const override {                                    // easing.rs:49-105
+        auto s = std::make_shared<Scene>();
+        s->lights.push_back(SphereLight({0, 0, 150}, Vec3::one(), 10.0));
+        s->lights.push_back(SphereLight({0, 1000, 150}, Vec3::one(), 10.0));
+        TexturePtr checker = CheckerTexture(ColorF::white(), ColorF::new_rgb(0.1, 0.1, 0.1), 32.0);
+        Material checker_mat = ct(0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.15, 0.0, 0.7, Vec3::one(), {0.6, 0.6, 0.6}, Vec3::one(), Vec3::zero(), checker);
+        s->prims.push_back(Plane(0.0, 0.0, 1.0, 0.0, boxed(checker_mat)));
+        s->background = {1, 1, 1};
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------------- my_scene/fresnel.rs
+struct FresnelConfig : Base {
+    using Base::Base;
+    Camera get_camera(uint32_t w, uint32_t h, double fov) const override {                // fresnel.rs:18-29
+        return Camera::create({50, 50, 250}, {50, 50, 50}, {0, 1, 0}, fov, w, h);
+    }
+    Camera get_animation_camera(uint32_t w, uint32_t h, double fov) const override {      // fresnel.rs:31-72
+        return Camera::new_with_keyframes({0, 1, 250}, {0, 1, 50}, {0, 1, 0}, fov, w, h,
+                                          {{2.5, {50, 100, 250}, {0, 1, 50}, {0, 1, 0}, Easing::linear()},
+                                           {5.0, {0, 200, 250}, {0, 1, 50}, {0, 1, 0}, Easing::linear()},
+                                           {7.5, {-50, 100, 250}, {0, 1, 50}, {0, 1, 0}, Easing::linear()},
+                                           {10.0, {0, 1, 250}, {0, 1, 50}, {0, 1, 0}, Easing::linear()}});
+    }
+    std::shared_ptr<Scene> get_scene() const override {                                    // fresnel.rs:74-101
+        auto s = std::make_shared<Scene>();
+        s->lights.push_back(SphereLight({50, 80, 50}, Vec3::one(), 10.0));
+        TexturePtr checker = CheckerTexture(ColorF::white(), ColorF::new_rgb(0.1, 0.1, 0.1), 32.0);
+        Material checker_red = ct(0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.15, 0.0, 1.5, Vec3::one(), {0.6, 0.6, 0.6}, Vec3::one(), Vec3::zero(), checker);
+        Material shiny = ct(0.0, 0.2, 1.0, 1.0, 0.0, 5.0, 0.01, 0.0, 0.15, Vec3::one(), {1, 1, 1}, {0.9, 0.9, 0.9}, Vec3::zero());
+        Material global_specular_only = ct(0.0, 0.0, 0.0, 1.0, 0.0, 5.0, 0.01, 0.0, 1.5, Vec3::one(), {1, 1, 1}, {0.9, 0.9, 0.9}, Vec3::zero());
+        Material refract = ct(0.0, 0.0, 1.0, 1.0, 1.0, 5.0, 0.01, 0.0, 3.0, Vec3::one(), {1, 1, 1}, {0.9, 0.9, 0.9}, Vec3::zero());
+        s->prims.push_back(Plane(0.0, 0.0, 1.0, 0.0, boxed(checker_red)));            // Ahead
+        s->prims.push_back(Plane(0.0, 1.0, 0.0, 0.0, boxed(global_specular_only)));   // Bottom
+        s->prims.push_back(Sphere({30, 15, 20}, 15.0, boxed(shiny)));
+        s->prims.push_back(Sphere({70, 17, 60}, 17.0, boxed(refract)));
+        s->background = {1, 1, 1};
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------------- my_scene/lucy.rs
+struct LucyConfig : Base {
+    using Base::Base;
+    Camera get_camera(uint32_t w, uint32_t h, double fov) const override {                // lucy.rs:15-24
+        return Camera::create({-1500, 300, 600}, {0, 400, -200}, {0, 1, 0}, fov, w, h);
+    }
+    std::shared_ptr<Scene> get_scene() const override {                                    // lucy.rs:26-53
+        auto s = std::make_shared<Scene>();
+        s->lights.push_back(SphereLight({-1400, 200, 100}, {1.0, 0.80, 0.40}, 50.0));
+        Material grey = ct(0.0, 0.5, 0.8, 0.5, 0.0, 5.0, 0.1, 0.0, 0.4, Vec3::one(), {0.6, 0.6, 0.65}, Vec3::one(), Vec3::zero());
+        if (!obj_or_nothing(grey, root, "lucy.obj", s->prims, true)) {
+            // stand-in ("50000 polys, model not included!", lucy.rs:14): a tall statue-like blob, 2*158*158 = 49 928 triangles
+            add_grid(s->prims, boxed(grey), blob({0, 420, -200}, 330.0, 0.2, 2.1, {0.55, 1.25, 0.55}), scaled(158, detail), scaled(158, detail));
+        }
+        s->background = {0.84, 0.34, 0.0};
+        s->skybox = skybox_or_standin(root, "storm_y_up", detail);
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------------- my_scene/tachikoma.rs
+struct TachikomaConfig : Base {
+    using Base::Base;
+    Camera get_camera(uint32_t w, uint32_t h, double fov) const override {                // tachikoma.rs:14-23
+        return Camera::create({100, 60, -150}, {0, 50, 0}, {0, 1, 0}, fov, w, h);
+    }
+    std::shared_ptr<Scene> get_scene() const override {                                    // tachikoma.rs:25-56
+        auto s = std::make_shared<Scene>();
+        s->lights.push_back(SphereLight({0, 100, 0}, {1, 1, 1}, 25.0));
+        Material blue = ct(0.0, 0.9, 1.0, 0.4, 0.0, 5.0, 0.01, 0.0, 0.25, Vec3::one(), {0.16, 0.29, 0.44}, Vec3::one(), Vec3::zero());
+        Material floor = ct(0.0, 0.9, 1.0, 1.0, 0.0, 5.0, 0.3, 0.0, 1.0, Vec3::one(), {0.58, 0.63, 0.44}, {0.9, 0.9, 0.9}, Vec3::zero());
+        s->prims.push_back(Plane(0.0, 1.0, 0.0, 0.0, boxed(floor)));   // Bottom
+        if (!obj_or_nothing(blue, root, "tachikoma.obj", s->prims, false)) {
+            // stand-in: a pod (body) on four leg blobs
+            MaterialPtr b = boxed(blue);
+            add_grid(s->prims, b, blob({0, 55, 0}, 32.0, 0.1, 0.4, {1.2, 0.9, 1.4}), scaled(64, detail), scaled(48, detail));
+            for (int k = 0; k < 4; ++k) {
+                double x = (k & 1) ? 34.0 : -34.0, z = (k & 2) ? 38.0 : -38.0;
+                add_grid(s->prims, b, blob({x, 22, z}, 14.0, 0.08, 0.9 * k, {0.8, 1.6, 0.8}), scaled(32, detail), scaled(24, detail));
+            }
+        }
+        s->background = {0.2, 0.2, 0.2};
+        s->skybox = skybox_or_standin(root, "city_y_up", detail);
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------------- my_scene/teapot.rs
+struct TeapotConfig : Base {
+    using Base::Base;
+    Camera get_camera(uint32_t w, uint32_t h, double fov) const override {                // teapot.rs:19-28
+        return Camera::create({-0.2, 1.0, 2.0}, {0, 0.6, 0}, {0, 1, 0}, fov, w, h);
+    }
+    std::shared_ptr<Scene> get_scene() const override {                                    // teapot.rs:30-62
+        auto s = std::make_shared<Scene>();
+        s->lights.push_back(SphereLight({0.6, 2.0, 1.2}, Vec3::one(), 1.0));
+        Material porcelain = ct(0.0, 0.9, 1.0, 1.0, 0.0, 5.0, 0.1, 0.0, 1.1, Vec3::one(), {0.9, 0.85, 0.7}, Vec3::one(), Vec3::zero());
+        Transform rotate(Mat4::rotate_x_deg_matrix(1.0));                                  // teapot.rs:39-40
+        if (!obj_or_nothing(porcelain, root, "teapot.obj", s->prims, false, &rotate)) {
+            // stand-in ("2500 polys", teapot.rs:18): a squat pot + a spout blob, through the same mut_transform
+            MaterialPtr m = boxed(porcelain);
+            add_grid_transformed(s->prims, m, blob({0, 0.55, 0}, 0.55, 0.05, 0.2, {1.25, 0.9, 1.25}), scaled(36, detail), scaled(28, detail), rotate);
+            add_grid_transformed(s->prims, m, blob({0.78, 0.7, 0}, 0.16, 0.1, 1.1, {1.9, 1.0, 0.7}), scaled(16, detail), scaled(12, detail), rotate);
+        }
+        s->background = {0.3, 0.5, 0.8};
+        s->skybox = skybox_or_standin(root, "miramar_y_up", detail);
+        return s;
+    }
+};
+
 } // namespace
 
 std::unique_ptr<SceneConfig> scene_by_name(const std::string &name, const std::string &asset_root, double detail) {
     if (name == "bunny") return std::unique_ptr<SceneConfig>(new BunnyConfig(asset_root, detail));
     if (name == "cornell") return std::unique_ptr<SceneConfig>(new CornellConfig(asset_root, detail));
+    if (name == "cow") return std::unique_ptr<SceneConfig>(new CowConfig(asset_root, detail));
+    if (name == "easing") return std::unique_ptr<SceneConfig>(new EasingConfig(asset_root, detail));
+    if (name == "fresnel") return std::unique_ptr<SceneConfig>(new FresnelConfig(asset_root, detail));
     if (name == "heptoroid-shiny") return std::unique_ptr<SceneConfig>(new HeptoroidConfig(asset_root, detail, 0));
     if (name == "heptoroid-refractive") return std::unique_ptr<SceneConfig>(new HeptoroidConfig(asset_root, detail, 1));
     if (name == "heptoroid-white") return std::unique_ptr<SceneConfig>(new HeptoroidConfig(asset_root, detail, 2));
+    if (name == "lucy") return std::unique_ptr<SceneConfig>(new LucyConfig(asset_root, detail));
     if (name == "sibenik") return std::unique_ptr<SceneConfig>(new SibenikConfig(asset_root, detail));
     if (name == "sphere") return std::unique_ptr<SceneConfig>(new SphereConfig(asset_root, detail));
     if (name == "sponza") return std::unique_ptr<SceneConfig>(new SponzaConfig(asset_root, detail));
-    // cow, easing, fresnel, lucy, tachikoma, teapot (my_scene/mod.rs:30-43): not on BASELINE.json's
-    // configs; same primitives and code paths — not yet transcribed.
-    return nullptr;
+    if (name == "tachikoma") return std::unique_ptr<SceneConfig>(new TachikomaConfig(asset_root, detail));
+    if (name == "teapot") return std::unique_ptr<SceneConfig>(new TeapotConfig(asset_root, detail));
+    return nullptr;   // my_scene/mod.rs:43: `_ => return None`
 }
 
 } // namespace rt

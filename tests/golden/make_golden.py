@@ -33,6 +33,9 @@ CASES = {
     "mesh_det": (scenes.mesh_scene, {}, (128, 96), DET),
     "mesh_transmissive_det": (scenes.mesh_scene, dict(transmissive=True, point_light=True), (96, 64), DET),
     "cube_det": (scenes.cube_obj_scene, {}, (64, 64), DET),
+    "kitchen_sink_det": (scenes.kitchen_sink_scene, {}, (104, 72), DET),
+    "kitchen_sink_points_philox": (scenes.kitchen_sink_scene, dict(lights="points"), (72, 56),
+                                   dict(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=2, rng_mode=1, seed=11)),
     "cornell_glossy_philox": (scenes.cornell_scene, dict(glossy=True), (64, 64), STO),
     "mesh_soft16_philox": (scenes.mesh_scene, {}, (96, 64),
                            dict(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=2, rng_mode=1, seed=3)),

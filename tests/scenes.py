@@ -139,3 +139,43 @@ def cube_obj_scene(rtx):
     b.background = (0.1, 0.2, 0.3)
     cam = lambda w, h, fov=30.0: rtx.camera((3, 2.5, 4), (0, 0, 0), (0, 1, 0), fov, w, h)
     return b.build(), cam
+
+
+def kitchen_sink_scene(rtx, lights="mixed"):
+    """Every material/texture/light kind the path has in one small scene: UV, image and checker textures on
+    Cook-Torrance and Phong, a FlatMaterial, a glossy-capable mirror, a transmissive sphere, point + sphere
+    lights (or none: `lights="none"`, or three point lights: `lights="points"`), finite prims of all kinds."""
+    b = rtx.SceneBuilder()
+    if lights == "mixed":
+        b.point_light((40, 90, 120), (0.7, 0.7, 0.6))
+        b.sphere_light((-30, 60, 80), (0.4, 0.5, 0.6), 12.0)
+    elif lights == "points":
+        b.point_light((40, 90, 120), (0.5, 0.5, 0.4))
+        b.point_light((-60, 40, 90), (0.3, 0.2, 0.2))
+        b.point_light((0, 150, 10), (0.2, 0.3, 0.4))
+    rng = np.random.RandomState(7)
+    img = np.zeros((9, 13, 4), dtype=np.uint8)          # odd, non-square image (bilinear x+1 / y+1 taps)
+    img[..., :3] = rng.randint(0, 256, size=(9, 13, 3))
+    img[..., 3] = 255
+    tex_img = b.image_texture(b.image(img))
+    tex_uv = b.uv_texture()
+    tex_chk = b.checker((0.9, 0.9, 0.2), (0.1, 0.1, 0.5), 0.25)
+    m_img = b.cook_torrance(k_a=0.05, k_d=0.8, k_s=0.3, gauss_constant=10.0, roughness=0.2, ior=1.4, diffuse=(1, 1, 1), diffuse_texture=tex_img)
+    m_uv = b.phong(k_a=0.1, k_d=0.8, k_s=0.5, shininess=20.0, ior=1.2, diffuse=(1, 1, 1), diffuse_texture=tex_uv)
+    m_chk = b.phong(k_d=0.7, k_s=0.2, k_sg=0.3, shininess=5.0, ior=0.6, diffuse=(0.8, 0.8, 0.8), diffuse_texture=tex_chk)
+    m_flat = b.flat((0.2, 0.9, 0.4))
+    m_mirror = b.cook_torrance(k_d=0.1, k_s=0.9, k_sg=0.9, gauss_constant=5.0, roughness=0.02, ior=0.3, diffuse=(0.9, 0.9, 1.0))
+    m_glass = b.cook_torrance(k_d=0.0, k_s=1.0, k_sg=1.0, k_tg=1.0, gauss_constant=5.0, roughness=0.01, ior=1.5,
+                              diffuse=(1, 1, 1), specular=(0.9, 0.9, 0.9), transmission=(0.7, 0.8, 0.9))
+    b.plane(0, 1, 0, 20, m_chk)                          # floor y = -20
+    b.plane(0, 0, 1, 60, m_img)                          # back wall z = -60
+    b.sphere((-35, 0, 0), 18.0, m_uv)
+    b.sphere((35, -2, 10), 16.0, m_glass)
+    b.sphere((0, 28, -20), 14.0, m_mirror)
+    v, n, uv = procedural_mesh(12, 8, radius=14.0, center=(0, -6, 25), seed=4)
+    b.triangles(v, m_img, normals=n, uv=uv)
+    b.triangle((-60, -20, 40), (-40, 25, 30), (-20, -20, 45), m_flat)
+    b.triangle((20, -20, 50), (40, 10, 45), (60, -20, 35), m_uv, uv=[(0.1, 0.9), (0.5, 0.1), (0.9, 0.8)])
+    b.background = (0.05, 0.07, 0.12)
+    cam = lambda w, h, fov=35.0: rtx.camera((0, 10, 140), (0, 0, 0), (0, 1, 0), fov, w, h)
+    return b.build(), cam

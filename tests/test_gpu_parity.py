@@ -285,3 +285,40 @@ def test_heptoroid_refractive_deep_recursion(rtx, orc):
     sc.close()
     _compare(rgba, ids, orgba, oids)
     assert st.rays_refract > 10000 and abs(int(st.rays_total) - int(ocn.rays_total)) <= 1e-3 * ocn.rays_total
+
+
+@pytest.mark.parametrize("lights,size", [("mixed", (104, 72)), ("points", (72, 56)), ("none", (40, 24))])
+def test_kitchen_sink_parity(rtx, orc, lights, size):
+    """UV / image / checker textures on both BRDFs, FlatMaterial, transmissive + mirror spheres, point and sphere
+    lights (also none at all, renderer.rs:114 folds over an empty list), widths that are not multiples of the
+    8-pixel wave tile or of the reference's 128-pixel tile (edge tiles over-render and merge clips, surface.rs:84-85)."""
+    flat, cam_fn = scenes.kitchen_sink_scene(rtx, lights=lights)
+    cam = cam_fn(*size)
+    opt = rtx.options(**DET)
+    orgba, oids, ocn = orc.Scene(flat).render(cam, opt)
+    sc = rtx.Scene(flat)
+    rgba, ids, st = sc.render(cam, opt)
+    sopt = rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=4, gloss_samples=1, pixel_samples=2, rng_mode=1, seed=11)
+    srgba, sids, sst = sc.render(cam, sopt)
+    sc.close()
+    _compare(rgba, ids, orgba, oids)
+    assert st.rays_total == ocn.rays_total or abs(int(st.rays_total) - int(ocn.rays_total)) <= 1e-3 * ocn.rays_total + 2
+    if lights == "none":
+        assert st.rays_shadow == 0
+    o2, oi2, _ = orc.Scene(flat).render(cam, sopt)
+    _compare(srgba, sids, o2, oi2, rgb_bar=0.995)
+
+
+@pytest.mark.parametrize("name,fov", [("cow", 45.0), ("easing", 30.0), ("fresnel", 30.0), ("lucy", 45.0), ("tachikoma", 45.0),
+                                      ("teapot", 45.0), ("heptoroid-shiny", 45.0), ("heptoroid-white", 45.0)])
+def test_registry_scenes_parity(rtx, orc, name, fov):
+    """The scenes of my_scene/mod.rs:28-44 that are not BASELINE configs, at reduced tessellation, against the oracle."""
+    named = rtx.host.NamedScene(name, detail=0.25)
+    cam = named.camera(96, 64, fov)
+    opt = rtx.options(**DET)
+    orgba, oids, ocn = orc.Scene(named).render(cam, opt, threads=16)
+    sc = rtx.Scene(named)
+    rgba, ids, st = sc.render(cam, opt)
+    sc.close()
+    _compare(rgba, ids, orgba, oids)
+    assert abs(int(st.rays_total) - int(ocn.rays_total)) <= 1e-3 * ocn.rays_total + 2

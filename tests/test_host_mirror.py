@@ -137,3 +137,45 @@ def test_sibenik_animation_camera(rtx):
     assert np.allclose(tuple(c7.position), (8.0, -13.5, 0.2)) and np.allclose(tuple(c7.up), (-0.9, 0.0, -0.7))
     mid = s.camera(64, 64, 45.0, time=3.5)
     assert np.allclose(tuple(mid.position), (-4.0, -14.0, -0.9))
+
+
+# my_scene/mod.rs:28-44: every name the reference's registry knows -> (planes, spheres, lights, camera position)
+REGISTRY = {
+    "bunny": (1, 2, 2, (0.0, -150.0, 30.0)), "cornell": (5, 4, 1, (50.0, 25.0, 150.0)), "cow": (1, 0, 1, (-2.0, 4.0, 10.0)),
+    "easing": (1, 0, 2, (0.0, 0.0, 150.0)), "fresnel": (2, 2, 1, (50.0, 50.0, 250.0)),
+    "heptoroid-shiny": (0, 0, 1, (7.0, 2.0, -6.0)), "heptoroid-white": (0, 0, 1, (7.0, 2.0, -6.0)),
+    "heptoroid-refractive": (0, 0, 1, (7.0, 2.0, -6.0)), "lucy": (0, 0, 1, (-1500.0, 300.0, 600.0)),
+    "sibenik": (1, 0, 3, (-16.0, -14.5, -2.0)), "sphere": (0, 1, 1, (0.0, 0.0, 10.0)), "sponza": (1, 0, 2, (800.0, 30.0, 90.0)),
+    "tachikoma": (1, 0, 1, (100.0, 60.0, -150.0)), "teapot": (0, 0, 1, (-0.2, 1.0, 2.0)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(REGISTRY))
+def test_registry_is_complete(rtx, name):
+    """All 14 names of scene_by_name (my_scene/mod.rs:28-44) resolve; prim/light lists and cameras as in the
+    reference's scene files (cow.rs, easing.rs, fresnel.rs, lucy.rs, tachikoma.rs, teapot.rs + the BASELINE five)."""
+    planes, spheres, lights, pos = REGISTRY[name]
+    s = rtx.host.NamedScene(name, detail=0.1)
+    assert (s.desc.n_planes, s.desc.n_spheres, len(s.lights)) == (planes, spheres, lights)
+    assert tuple(s.camera(64, 64, 30.0).position) == pos
+    mesh_scenes = {"bunny", "cornell", "cow", "lucy", "sibenik", "sponza", "tachikoma", "teapot"} | {n for n in REGISTRY if n.startswith("hept")}
+    assert (s.n_triangles > 0) == (name in mesh_scenes)
+
+
+def test_easing_scene_animation_camera(rtx):
+    """easing.rs:29-47: one keyframe at 10 s with Easing{0, 0.05, 0.1, 1}; end points are exact."""
+    s = rtx.host.NamedScene("easing")
+    c0, c10 = s.camera(64, 64, 30.0, time=0.0), s.camera(64, 64, 30.0, time=10.0)
+    assert tuple(c0.position) == (0.0, 0.0, 150.0) and np.allclose(tuple(c10.position), (0.0, 1000.0, 150.0))
+    mid = s.camera(64, 64, 30.0, time=5.0)
+    want = rtx.host.easing_t(0.5, 0.0, 0.05, 0.1, 1.0) * 1000.0
+    assert np.isclose(mid.position[1], want) and mid.position[1] < 500.0      # slow start
+
+
+def test_teapot_goes_through_mut_transform(rtx):
+    """teapot.rs:39-40: the mesh is rotated by rotate_x_deg_matrix(1.0) before it enters the octree."""
+    s = rtx.host.NamedScene("teapot", detail=0.25)
+    v = np.ctypeslib.as_array(s.desc.tri_vertices, shape=(s.n_triangles, 3, 3))
+    # the stand-in pot is symmetric about z = 0 before the rotation: the 1 degree tilt about x couples z to y
+    zc = v[..., 2].mean()
+    assert abs(zc) > 1e-3

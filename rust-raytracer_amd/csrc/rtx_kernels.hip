@@ -1209,6 +1209,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
 #ifndef RTX_COOP_WAVES
 #define RTX_COOP_WAVES 5
 #endif
+#define RTX_COOP_PAIRS 128    // 63 waiting + 64 pushed in one step at most
+#ifndef RTX_COOP_PT
+#define RTX_COOP_PT 1         // after a queue drain, run the exact tests once this many pairs wait
+#endif
 DEV float f32_below(double v) {   // a float <= v
     float f = (float)v;
     return f - fabsf(f) * 1.1920929e-7f;
@@ -1260,6 +1264,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // turn them into flat, cache-bypassing accesses)
     __shared__ uint32_t s_stack[RTX_BLOCK / 16][RTX_COOP_STACK];
     __shared__ uint32_t s_queue[RTX_BLOCK / 16][RTX_COOP_QUEUE];
+    // wave-shared: (primitive ref, owner lane | surely_in << 6) pairs that passed the owner's f32 box test and
+    // wait for the exact f64 tests; s_hit[lane] != 0 once an exact test has found an occluder for that lane's ray
+    __shared__ uint2 s_pair[RTX_BLOCK / 64][RTX_COOP_PAIRS];
+    __shared__ uint32_t s_hit[RTX_BLOCK];
+    // every lane's feeler (origin, direction, inverse direction), read back by the lane that runs its exact tests
+    __shared__ double s_ray[9][RTX_BLOCK];
+    // each group's beam (11 floats), re-read at every node step: they would otherwise sit in registers during the
+    // exact tests, where the pressure peaks, and be spilled to scratch memory
+    __shared__ float s_beam[RTX_BLOCK / 16][12];
 #define COOP_FENCE() asm volatile("" ::: "memory")
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
@@ -1376,6 +1389,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         m1L = m1H = m2L = m2H = 0.0f;
         umax_w = 1.0f;
     }
+    if (l16 == 0u) {
+        float *bm = s_beam[sub];
+        bm[0] = o0min; bm[1] = o0max; bm[2] = o1min; bm[3] = o1max; bm[4] = o2min; bm[5] = o2max;
+        bm[6] = m1L; bm[7] = m1H; bm[8] = m2L; bm[9] = m2H; bm[10] = umax_w;
+    }
+    COOP_FENCE();
 #define COOP_STK(i) s_stack[sub][(i)]   /* spilled levels: 2 words each (first node, kind16 << 16 | pending16) */
 #define COOP_QUE(i) s_queue[sub][(i)]
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -1392,6 +1411,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
 
     // beam-vs-box test of one child record (see the comment above the beam set-up)
     auto keep_box = [&](const float4 &qa, const float4 &qb) -> bool {
+        const float *bm = s_beam[sub];
+        const float o0min = bm[0], o0max = bm[1], o1min = bm[2], o1max = bm[3], o2min = bm[4], o2max = bm[5];
+        const float m1L = bm[6], m1H = bm[7], m2L = bm[8], m2H = bm[9], umax_w = bm[10];
         const float c0l = a0 == 0 ? qa.x : (a0 == 1 ? qa.y : qa.z), c0h = a0 == 0 ? qa.w : (a0 == 1 ? qb.x : qb.y);
         const float c1l = a1 == 0 ? qa.x : qa.y, c1h = a1 == 0 ? qa.w : qb.x;
         const float c2l = a2 == 1 ? qa.y : qa.z, c2h = a2 == 1 ? qb.x : qb.y;
@@ -1416,6 +1438,61 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const uint32_t slot = (uint32_t)__ffs((int)pend) - 1u;
         tmask &= ~(1u << slot);
         return tfirst + (uint32_t)__popc((tmask >> 16) & ((1u << slot) - 1u));
+    };
+
+    // Exact tests of up to 64 waiting pairs, one per lane (octree.rs:170 + renderer.rs:212 on the owner's ray,
+    // read back from LDS).  Must be called by all 64 lanes.
+    const uint32_t wid = threadIdx.x >> 6;
+    uint32_t pair_n = 0u;           // wave-uniform
+    s_hit[threadIdx.x] = 0u;
+    s_ray[0][threadIdx.x] = r.ox; s_ray[1][threadIdx.x] = r.oy; s_ray[2][threadIdx.x] = r.oz;
+    s_ray[3][threadIdx.x] = r.dx; s_ray[4][threadIdx.x] = r.dy; s_ray[5][threadIdx.x] = r.dz;
+    s_ray[6][threadIdx.x] = r.ix; s_ray[7][threadIdx.x] = r.iy; s_ray[8][threadIdx.x] = r.iz;
+    COOP_FENCE();
+    auto run_pairs = [&]() {
+        const uint32_t n = pair_n < 64u ? pair_n : 64u;
+        pair_n -= n;
+        const bool mine = lane < n;
+        const uint2 pr = s_pair[wid][pair_n + (mine ? lane : 0u)];
+        const uint32_t owner = (threadIdx.x & ~63u) + (pr.y & 63u);
+        const double q_dist = __shfl(distance_to_light, (int)(pr.y & 63u));
+        if (mine && s_hit[owner] == 0u) {
+            Ray q;
+            q.ox = s_ray[0][owner]; q.oy = s_ray[1][owner]; q.oz = s_ray[2][owner];
+            q.dx = s_ray[3][owner]; q.dy = s_ray[4][owner]; q.dz = s_ray[5][owner];
+            q.ix = q.iy = q.iz = 0.0; q.sx = q.sy = q.sz = true; q.flip = 0u;   // read by the entry-bbox tests only
+            // the inverse direction is fetched only where the exact entry-bbox test runs (keeps the primitive
+            // tests' register peak down)
+            auto entry_ray = [&]() {
+                Ray e = q;
+                e.ix = s_ray[6][owner]; e.iy = s_ray[7][owner]; e.iz = s_ray[8][owner];
+                e.sx = e.ix > 0.0; e.sy = e.iy > 0.0; e.sz = e.iz > 0.0;
+                return e;
+            };
+            const bool surely_in = (pr.y & 64u) != 0u;
+            const uint32_t idx = pr.x & RTX_WREF_INDEX;
+            bool occluded = false;
+            if ((pr.x & RTX_WREF_KIND) == RTX_WREF_TRI) {
+                int pid, mat;
+                TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
+                if (surely_in || tri_bbox_hit(tr, entry_ray())) {
+                    WORK(++w_prims;)
+                    double t, be, ga;
+                    occluded = tri_hit(tr, q, EPSILON, q_dist, &t, &be, &ga);
+                }
+            } else {
+                const DSphere &sp_ = sc.spheres[idx];
+                V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                if (surely_in || sphere_bbox_hit(cc, sp_.r, entry_ray())) {
+                    WORK(++w_prims;)
+                    double t;
+                    occluded = sphere_hit(cc, sp_.r, q, EPSILON, q_dist, &t);
+                }
+            }
+            if (occluded) s_hit[owner] = 1u;
+        }
+        COOP_FENCE();
+        if (s_hit[threadIdx.x] != 0u) { alive = false; seek = false; }
     };
 
     for (;;) {
@@ -1454,26 +1531,23 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             tmask = nA ? ((kA << 16) | nA) : tmask;
             COOP_FENCE();
         }
-        // ---- drain the candidate queues: every lane tests the primitive against its OWN ray
+        // ---- drain the candidate queues: every lane tests the primitive's box against its OWN ray in f32; the
+        // (ray, primitive) pairs that survive are appended to the wave's pair list, and the exact f64 tests then
+        // run on up to 64 pairs at a time, one pair per lane whoever owns the ray.  Tested in place, a primitive
+        // would keep only the lanes whose ray passes its box busy (measured: 17 of 64 on average).
         const bool walk_over = (tmask & 0xFFFFu) == 0u && sp == 0u;
         const bool want_x = g_on && (qn >= RTX_COOP_QT || (walk_over && qn > 0u));
         if (__any(want_x)) {
             while (__any(qn > 0u)) {
+                bool push = false;
+                uint32_t pref = 0u, powner = lane;
                 if (qn > 0u) {
                     --qn;
                     COOP_FENCE();
                     const uint32_t c = COOP_QUE(qn);
-#ifdef RTX_EXP_COOP_NOX
-                    if (c == 0xFFFFFFFFu)      // timing experiment: no per-ray tests at all (wrong images)
-#elif defined(RTX_EXP_COOP_NOEXACT)
-                    if (alive && c == 0xFFFFFFFFu)
-#else
-                    if (seek)
-#endif
-                    {
+                    if (seek) {
                         const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
                         const float4 c_lo = pc[0], c_hi = pc[1];
-                        const uint32_t ref = __float_as_uint(c_hi.z);
                         const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
                         WORK(++w_entries;)
                         const float enx = sx ? lx : ux, efx = sx ? ux : lx;
@@ -1482,34 +1556,29 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                         const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
                         const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), tmax_own), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
                         if (lo <= hi) {
+                            // the box shrunk by delta instead of widened: a ray through it passes the exact f64
+                            // entry test (octree.rs:170) with a margin far above f64 rounding
                             bool surely_in = false;
                             if (finite_dir) {
                                 const float li = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
                                 const float hi2 = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
                                 surely_in = li <= hi2 && hi2 > 0.0f;
                             }
-                            const uint32_t idx = ref & RTX_WREF_INDEX;
-                            if ((ref & RTX_WREF_KIND) == RTX_WREF_TRI) {
-                                int pid, mat;
-                                TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
-                                if (surely_in || tri_bbox_hit(tr, r)) {
-                                    WORK(++w_prims;)
-                                    double t, be, ga;
-                                    if (tri_hit(tr, r, EPSILON, distance_to_light, &t, &be, &ga)) { alive = false; seek = false; }
-                                }
-                            } else {
-                                const DSphere &sp_ = sc.spheres[idx];
-                                V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
-                                if (surely_in || sphere_bbox_hit(cc, sp_.r, r)) {
-                                    WORK(++w_prims;)
-                                    double t;
-                                    if (sphere_hit(cc, sp_.r, r, EPSILON, distance_to_light, &t)) { alive = false; seek = false; }
-                                }
-                            }
+                            push = true;
+                            pref = __float_as_uint(c_hi.z);
+                            powner = lane | (surely_in ? 64u : 0u);
                         }
                     }
                 }
+                const unsigned long long pm = __ballot(push);
+                if (pm != 0ull) {
+                    if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(pref, powner);
+                    pair_n += (uint32_t)__popcll(pm);
+                    COOP_FENCE();
+                    if (pair_n >= 64u) run_pairs();
+                }
             }
+            if (pair_n >= RTX_COOP_PT) run_pairs();
             a16 = (uint32_t)(__ballot(seek) >> gbase) & 0xFFFFu;
             if (!a16) { sp = 0u; tmask = 0u; }   // every feeler of the group is occluded
         }
@@ -1522,19 +1591,23 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         }
     }
 
+    while (pair_n > 0u) run_pairs();   // what the last drains left waiting (RTX_COOP_PT > 1 only)
     // infinite prims (planes), octree.rs:163-165: a feeler that is still clear tests them in order
     if (alive) {
+        Ray q;      // the lane's own feeler again (kept in LDS, not in registers, during the walk)
+        q.ox = s_ray[0][threadIdx.x]; q.oy = s_ray[1][threadIdx.x]; q.oz = s_ray[2][threadIdx.x];
+        q.dx = s_ray[3][threadIdx.x]; q.dy = s_ray[4][threadIdx.x]; q.dz = s_ray[5][threadIdx.x];
         for (int p = 0; p < sc.n_planes; ++p) {
             double t;
-            if (plane_hit(sc.planes[p], r, EPSILON, distance_to_light, &t)) { alive = false; break; }
+            if (plane_hit(sc.planes[p], q, EPSILON, distance_to_light, &t)) { alive = false; break; }
         }
     }
 #ifdef RTX_COUNT_WORK
     if (valid) {
         atomicAdd(&counters->work[1][0], (unsigned long long)w_nodes);
         atomicAdd(&counters->work[1][1], (unsigned long long)w_entries);
-        atomicAdd(&counters->work[1][2], (unsigned long long)w_prims);
     }
+    atomicAdd(&counters->work[1][2], (unsigned long long)w_prims);   // exact tests are run by whichever lane took the pair
 #endif
     V3 v = (valid && alive) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
     double inv_tries = 1.0 / (double)tries;
@@ -1547,9 +1620,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             v.z += __shfl_xor(v.z, (int)off);
         }
     }
-    if (valid && (k == 0u || !pow2_tries)) {
-        uint32_t g2 = group;
-        asm volatile("" : "+v"(g2));   // fresh loads, not the prologue's values kept alive
+    uint32_t t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));   // group / try index and loads afresh, not the prologue's values kept alive
+    const uint64_t gid2 = (uint64_t)blockIdx.x * RTX_BLOCK + t2;
+    if (valid && (gid2 % tries == 0u || !pow2_tries)) {
+        const uint32_t g2 = (uint32_t)(gid2 / tries);
         const double *f = sq.f + (size_t)light * 6 * qc + g2;
         acc_add(acc, sq.sample[(size_t)light * qc + g2], v3(f[3 * qc], f[4 * qc], f[5 * qc]) * scale(v, inv_tries));   // renderer.rs:220,118
     }

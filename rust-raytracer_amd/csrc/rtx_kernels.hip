@@ -1269,7 +1269,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     __shared__ uint2 s_pair[RTX_BLOCK / 64][RTX_COOP_PAIRS];
     __shared__ uint32_t s_hit[RTX_BLOCK];
     // every lane's feeler (origin, direction, inverse direction), read back by the lane that runs its exact tests
-    __shared__ double s_ray[9][RTX_BLOCK];
+    __shared__ double s_ray[6][RTX_BLOCK];      // direction, inverse direction per lane
+    __shared__ double s_org[3][RTX_BLOCK / 16]; // origin: one hit point per group (tries is a multiple of 16)
     // each group's beam (11 floats), re-read at every node step: they would otherwise sit in registers during the
     // exact tests, where the pressure peaks, and be spilled to scratch memory
     __shared__ float s_beam[RTX_BLOCK / 16][12];
@@ -1445,9 +1446,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     const uint32_t wid = threadIdx.x >> 6;
     uint32_t pair_n = 0u;           // wave-uniform
     s_hit[threadIdx.x] = 0u;
-    s_ray[0][threadIdx.x] = r.ox; s_ray[1][threadIdx.x] = r.oy; s_ray[2][threadIdx.x] = r.oz;
-    s_ray[3][threadIdx.x] = r.dx; s_ray[4][threadIdx.x] = r.dy; s_ray[5][threadIdx.x] = r.dz;
-    s_ray[6][threadIdx.x] = r.ix; s_ray[7][threadIdx.x] = r.iy; s_ray[8][threadIdx.x] = r.iz;
+    if (l16 == 0u) { s_org[0][sub] = r.ox; s_org[1][sub] = r.oy; s_org[2][sub] = r.oz; }
+    s_ray[0][threadIdx.x] = r.dx; s_ray[1][threadIdx.x] = r.dy; s_ray[2][threadIdx.x] = r.dz;
+    s_ray[3][threadIdx.x] = r.ix; s_ray[4][threadIdx.x] = r.iy; s_ray[5][threadIdx.x] = r.iz;
     COOP_FENCE();
     auto run_pairs = [&]() {
         const uint32_t n = pair_n < 64u ? pair_n : 64u;
@@ -1458,14 +1459,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const double q_dist = __shfl(distance_to_light, (int)(pr.y & 63u));
         if (mine && s_hit[owner] == 0u) {
             Ray q;
-            q.ox = s_ray[0][owner]; q.oy = s_ray[1][owner]; q.oz = s_ray[2][owner];
-            q.dx = s_ray[3][owner]; q.dy = s_ray[4][owner]; q.dz = s_ray[5][owner];
+            q.ox = s_org[0][owner >> 4]; q.oy = s_org[1][owner >> 4]; q.oz = s_org[2][owner >> 4];
+            q.dx = s_ray[0][owner]; q.dy = s_ray[1][owner]; q.dz = s_ray[2][owner];
             q.ix = q.iy = q.iz = 0.0; q.sx = q.sy = q.sz = true; q.flip = 0u;   // read by the entry-bbox tests only
             // the inverse direction is fetched only where the exact entry-bbox test runs (keeps the primitive
             // tests' register peak down)
             auto entry_ray = [&]() {
                 Ray e = q;
-                e.ix = s_ray[6][owner]; e.iy = s_ray[7][owner]; e.iz = s_ray[8][owner];
+                e.ix = s_ray[3][owner]; e.iy = s_ray[4][owner]; e.iz = s_ray[5][owner];
                 e.sx = e.ix > 0.0; e.sy = e.iy > 0.0; e.sz = e.iz > 0.0;
                 return e;
             };
@@ -1595,8 +1596,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // infinite prims (planes), octree.rs:163-165: a feeler that is still clear tests them in order
     if (alive) {
         Ray q;      // the lane's own feeler again (kept in LDS, not in registers, during the walk)
-        q.ox = s_ray[0][threadIdx.x]; q.oy = s_ray[1][threadIdx.x]; q.oz = s_ray[2][threadIdx.x];
-        q.dx = s_ray[3][threadIdx.x]; q.dy = s_ray[4][threadIdx.x]; q.dz = s_ray[5][threadIdx.x];
+        q.ox = s_org[0][sub]; q.oy = s_org[1][sub]; q.oz = s_org[2][sub];
+        q.dx = s_ray[0][threadIdx.x]; q.dy = s_ray[1][threadIdx.x]; q.dz = s_ray[2][threadIdx.x];
         for (int p = 0; p < sc.n_planes; ++p) {
             double t;
             if (plane_hit(sc.planes[p], q, EPSILON, distance_to_light, &t)) { alive = false; break; }
@@ -1727,11 +1728,7 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
     // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
     // wide (a ground plane seen near the horizon) and walk most of the hierarchy
-#ifdef RTX_EXP_COOP_ANY_TRIES
-    const bool single_origin = true;     // timing experiment: groups of 16 consecutive feelers whatever their hit points
-#else
-    const bool single_origin = tries % 16u == 0u;
-#endif
+    const bool single_origin = tries % 16u == 0u;   // k_shadow_coop relies on it (one origin per group in LDS)
     if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && single_origin)
         hipLaunchKernelGGL(k_shadow_coop, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, n_groups,
                            tries, pow2, counters, acc);

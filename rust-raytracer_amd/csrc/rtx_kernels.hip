@@ -421,7 +421,7 @@ DEV void traverse_exact(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, st
     else *prod = acc;
 }
 
-// Fast traversal for MODE_CLOSEST and MODE_ANY.  Node and leaf-entry boxes are tested in f32
+// Fast traversals (closest hit: traverse_closest_ww, any hit: traverse_any_fast and k_shadow_coop).  Node and leaf-entry boxes are tested in f32
 // against the outward-rounded DNode32 / DEntry32 twins, widened by a per-ray delta that bounds
 // every rounding error of the f32 arithmetic (origin and inverse direction rounded to f32, one
 // subtraction and one multiplication per plane: < 2^-22 * S in position units, S = largest
@@ -478,11 +478,11 @@ DEV void init_lds(uint32_t *s_lds) {
     }
     __syncthreads();
 }
-template <int MODE>
-DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
+// Any-hit walk of one shadow feeler per lane over the octree (k_shadow<MODE_ANY>: all-opaque scenes whose
+// feeler groups the cooperative kernel does not take): stop at the first occluder inside [t_lo, t_hi].
+DEV void traverse_any_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
     uint32_t *stk = s_lds + threadIdx.x;   // level stack, stride RTX_BLOCK
     const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
-    double best_t = t_hi;
     int best_ref = REF_NONE;
     bool done = false;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
@@ -505,7 +505,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     const uint32_t flip = r.flip;
     const uint8_t *perm_row = perm + (flip << 8);
-    float bf = f32_above(best_t - tsh);   // upper bound of best_t (shifted) for the f32 culls
+    const float bf = f32_above(t_hi - tsh);   // upper bound of the feeler's length (shifted) for the f32 culls
     int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
 
     int sp = 0;
@@ -522,6 +522,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
             stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
             cur = (e >> 8) + (j ^ flip);
         }
+        have_cur = false;
         const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
         const float4 qa = nq[0], qb = nq[1];
         const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
@@ -531,11 +532,6 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
         const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
         const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
         const float t0x = fmaf(pnx, ix, cnx), t0y = fmaf(pny, iy, cny), t0z = fmaf(pnz, iz, cnz);
-        if (!have_cur) {
-            // the parent found this box hit; cull it if it now starts behind the best hit
-            if (fmaxf(fmaxf(t0x, t0y), t0z) > bf) continue;
-        }
-        have_cur = false;
 
         if (aux == 0xFFFFFFFFu) {
             // child boxes = halves of this box (octree.rs:79-92); the f64 mid planes max - len/2 and
@@ -560,9 +556,6 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
             }
         } else {
             const DEntry32 *ep = sc.entries32 + link;
-#ifdef RTX_EXP_NOE
-            if (MODE == MODE_ANY && aux) continue;   // timing experiment only: drop the leaf entry loop (wrong images)
-#endif
             for (uint32_t e = 0; e < aux; ++e) {
                 const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
                 const float4 ea = eq[0], eb = eq[1];
@@ -577,10 +570,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
                     if (!(lo <= hi)) continue;
                 }
                 const int ref = __float_as_int(eb.z);
-#ifdef RTX_EXP_NOX
-                if (MODE == MODE_ANY) continue;   // timing experiment only: drop the exact tests (wrong images)
-#endif
-                if (ref == last_ref0 || ref == last_ref1) continue;   // already tested with a window at least as wide
+                if (ref == last_ref0 || ref == last_ref1) continue;   // already tested with the same window
                 last_ref1 = last_ref0;
                 last_ref0 = ref;
                 // the box shrunk by delta instead of widened: a ray through it passes the exact f64
@@ -597,16 +587,7 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
                     if (!surely_in && !tri_bbox_hit(tr, r)) continue;
                     WORK(++w_prims;)
                     double t, be, ga;
-                    if (MODE == MODE_CLOSEST) {
-                        // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
-                        if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
-                            best_t = t;
-                            best_ref = ref;
-                            bf = f32_above(best_t - tsh);
-                        }
-                    } else if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
-                        best_ref = ref; done = true; break;
-                    }
+                    if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) { best_ref = ref; done = true; break; }
                 } else {
                     const DSphere &sp_ = sc.spheres[~ref];
                     V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
@@ -614,51 +595,240 @@ DEV void traverse_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t
                     if (!surely_in && !sphere_bbox_hit(c, radius, r)) continue;
                     WORK(++w_prims;)
                     double t;
-                    if (MODE == MODE_CLOSEST) {
-                        if (sphere_hit(c, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
-                            best_t = t;
-                            best_ref = ref;
-                            bf = f32_above(best_t - tsh);
-                        }
-                    } else if (sphere_hit(c, radius, r, t_lo, t_hi, &t)) {
-                        best_ref = ref; done = true; break;
-                    }
+                    if (sphere_hit(c, radius, r, t_lo, t_hi, &t)) { best_ref = ref; done = true; break; }
                 }
-            }
-            // near-to-far: everything still pending starts behind this leaf's exit.  The exit is
-            // taken with delta the OTHER way (cn on a far plane), i.e. a lower bound of the true exit.
-            if (MODE == MODE_CLOSEST && best_ref != REF_NONE) {
-                float exit_lo = fminf(fminf(fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny)), fmaf(pfz, iz, cnz));
-                if (finite_dir && best_t - tsh <= (double)exit_lo) done = true;
             }
         }
     }
 
     // infinite prims last, in order (octree.rs:163-165,185-186)
-    if (!(MODE == MODE_ANY && done && !skip_finite)) {
+    if (!(done && !skip_finite)) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            double t;
+            if (plane_hit(sc.planes[p], r, t_lo, t_hi, &t)) { best_ref = REF_PLANE | p; break; }
+        }
+    }
+    hit->t = t_hi;
+    hit->ref = best_ref;
+    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
+    *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+}
+
+// Closest hit as a WHILE-WHILE walk with DEFERRED exact tests (k_closest, k_nearest).  Same nodes, same
+// conservative f32 tests and same exact f64 tests as the per-lane any-hit walk above, arranged so that the lanes of
+// a wave do the same kind of work at the same time:
+//   phase 1  every lane descends the octree until it stands in a leaf (or its walk is over);
+//   phase 2  every lane scans its leaf's entries; a candidate that passes the f32 entry test is PARKED in a
+//            small per-lane LDS buffer instead of being tested on the spot;
+//   phase 3  when a buffer is full, enough lanes hold candidates or nobody walks any more, the wave tests the
+//            parked candidates, every lane one of its OWN per round, in visiting order.
+// With "node or whole leaf per iteration" and tests in place, one lane's leaf loop or 200-instruction f64 test
+// held the other 63 lanes (measured: 29 % of the lanes active).  Between flushes a lane walks on with a stale
+// best t: that only weakens the culling (Appendix A); a lane finishes after a flush, when best t <= exit of
+// the last leaf it has completed (near-to-far order: everything still pending starts behind that exit).
+// Must be called by every lane of the wave that has not left the kernel; `active` = the lane has a ray.
+#ifndef RTX_DEFER_CAP
+#define RTX_DEFER_CAP 4       // candidates a lane can park
+#endif
+#ifndef RTX_DEFER_FLUSH
+#define RTX_DEFER_FLUSH 24    // flush once this many lanes hold parked candidates
+#endif
+#define RTX_CAND_WORDS (RTX_DEFER_CAP * RTX_BLOCK)
+#ifndef RTX_ENTRY_BATCH
+#define RTX_ENTRY_BATCH 4     // leaf entries fetched together
+#endif
+DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, Hit *hit) {
+    uint32_t *stk = s_lds + threadIdx.x;     // level stack, stride RTX_BLOCK
+    uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
+    const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
+    double best_t = inf();
+    int best_ref = REF_NONE;
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
+
+    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh
+    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
+    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+    const double delta = big * (1.0 / 1048576.0);
+    const bool sx = r.sx, sy = r.sy, sz = r.sz;
+    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
+    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
+    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
+    const uint32_t flip = r.flip;
+    const uint8_t *perm_row = perm + (flip << 8);
+    float bf = f32_above(best_t - tsh);
+    int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
+
+    int sp = 0;
+    bool at_root = true;                       // root: never culled (octree.rs:149,177)
+    bool running = active && !re.miss;         // a ray that misses the scene's cube has no finite candidate
+    uint32_t cnt = 0;                          // parked candidates
+    uint32_t e_cur = 0, e_end = 0;             // position in the current leaf's entry list (absolute indices)
+    const float NEG_INF = __int_as_float(0xFF800000);
+    float cur_exit = NEG_INF, last_exit = NEG_INF;   // lower bounds of the exit distance of the current / last completed leaf
+
+    for (;;) {
+        if (!__any(running || cnt > 0u)) break;
+        // ---- phase 1: descend until the lane stands in a non-empty leaf or its walk is over
+        while (running && e_cur >= e_end) {
+            uint32_t cur = 0;
+            if (!at_root) {
+                while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
+                if (sp == 0) { running = false; break; }
+                uint32_t e = stk[(sp - 1) * RTX_BLOCK];
+                uint32_t j = (uint32_t)__ffs((int)(e & 0xFFu)) - 1u;
+                stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
+                cur = (e >> 8) + (j ^ flip);
+            }
+            const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
+            const float4 qa = nq[0], qb = nq[1];
+            const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
+            const uint32_t link = __float_as_uint(qb.z), aux = __float_as_uint(qb.w);
+            const float pnx = sx ? minx : maxx, pfx = sx ? maxx : minx;
+            const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
+            const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
+            const float t0x = fmaf(pnx, ix, cnx), t0y = fmaf(pny, iy, cny), t0z = fmaf(pnz, iz, cnz);
+            // the parent found this box hit; cull it if it now starts behind the best hit
+            const bool culled = !at_root && fmaxf(fmaxf(t0x, t0y), t0z) > bf;
+            at_root = false;
+            if (culled) continue;
+            WORK(++w_nodes;)
+            if (aux == 0xFFFFFFFFu) {
+                // child boxes = halves of this box (octree.rs:79-92), see traverse_any_fast
+                const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
+                const float n0x = fmaxf(t0x, 0.0f), n1x = fmaxf(fmaf(mx, ix, cnx), 0.0f);
+                const float f0x = fminf(fmaf(mx, ix, cfx), bf), f1x = fminf(fmaf(pfx, ix, cfx), bf);
+                const float n0y = t0y, n1y = fmaf(my, iy, cny), f0y = fmaf(my, iy, cfy), f1y = fmaf(pfy, iy, cfy);
+                const float n0z = t0z, n1z = fmaf(mz, iz, cnz), f0z = fmaf(mz, iz, cfz), f1z = fmaf(pfz, iz, cfz);
+                uint32_t pending = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    float lo = fmaxf(fmaxf((j & 4u) ? n1x : n0x, (j & 2u) ? n1y : n0y), (j & 1u) ? n1z : n0z);
+                    float hi = fminf(fminf((j & 4u) ? f1x : f0x, (j & 2u) ? f1y : f0y), (j & 1u) ? f1z : f0z);
+                    pending |= (lo <= hi) ? (1u << j) : 0u;
+                }
+                pending &= (uint32_t)perm_row[link & 0xFFu];
+                if (pending) {
+                    stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
+                    ++sp;
+                }
+            } else {
+                // exit taken with delta the OTHER way (cn on a far plane): a lower bound of the true exit
+                cur_exit = finite_dir ? fminf(fminf(fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny)), fmaf(pfz, iz, cnz)) : NEG_INF;
+                e_cur = link;
+                e_end = link + aux;
+                if (aux == 0u) last_exit = cur_exit;
+            }
+        }
+        // ---- phase 2: the leaf's entries, until it is finished or the lane's buffer is full.  The walk is bound by
+        // memory latency (one dependent load per step), so the boxes of up to RTX_ENTRY_BATCH entries are fetched
+        // together before any of them is tested.
+        while (running && e_cur < e_end && cnt < RTX_DEFER_CAP) {
+            float4 ea_[RTX_ENTRY_BATCH], eb_[RTX_ENTRY_BATCH];
+            const uint32_t nb = e_end - e_cur;
+#pragma unroll
+            for (uint32_t k = 0; k < RTX_ENTRY_BATCH; ++k) {
+                const float4 *eq = reinterpret_cast<const float4 *>(sc.entries32 + e_cur + (k < nb ? k : 0u));
+                ea_[k] = eq[0];
+                eb_[k] = eq[1];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < RTX_ENTRY_BATCH; ++k) {
+                if (k < nb && cnt < RTX_DEFER_CAP) {
+                    const float4 ea = ea_[k], eb = eb_[k];
+                    ++e_cur;
+                    WORK(++w_entries;)
+                    // conservative f32 version of the entry's own bbox test (octree.rs:170)
+                    const float enx = sx ? ea.x : ea.w, efx = sx ? ea.w : ea.x;
+                    const float eny = sy ? ea.y : eb.x, efy = sy ? eb.x : ea.y;
+                    const float enz = sz ? ea.z : eb.y, efz = sz ? eb.y : ea.z;
+                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
+                    const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), bf), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
+                    const int ref = __float_as_int(eb.z);
+                    // mailbox: already parked or tested with a window at least as wide
+                    if (lo <= hi && ref != last_ref0 && ref != last_ref1) {
+                        last_ref1 = last_ref0;
+                        last_ref0 = ref;
+                        // the box shrunk by delta instead of widened: a ray through it passes the exact f64 entry
+                        // test with a margin far above f64 rounding, so that test can be skipped
+                        bool surely_in = false;
+                        if (finite_dir) {
+                            float li = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
+                            float hi2 = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
+                            surely_in = li <= hi2 && hi2 > 0.0f;
+                        }
+                        cand[cnt * RTX_BLOCK] = ((uint32_t)ref << 1) | (surely_in ? 1u : 0u);
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        if (running && e_cur >= e_end) last_exit = cur_exit;   // leaf completed
+        // ---- phase 3: flush
+        const bool stalled = running && e_cur < e_end;   // buffer full in mid-leaf
+        const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
+        if (__any(stalled) || holders >= RTX_DEFER_FLUSH || !__any(running)) {
+            for (uint32_t i = 0; __any(i < cnt); ++i) {
+                if (i < cnt) {
+                    const uint32_t c = cand[i * RTX_BLOCK];
+                    const int ref = (int)c >> 1;
+                    const bool surely_in = (c & 1u) != 0u;
+                    if (ref >= 0) {
+                        int pid, mat;
+                        TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                        if (surely_in || tri_bbox_hit(tr, r)) {
+                            WORK(++w_prims;)
+                            double t, be, ga;
+                            // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
+                            if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                                best_t = t;
+                                best_ref = ref;
+                            }
+                        }
+                    } else {
+                        const DSphere &sp_ = sc.spheres[~ref];
+                        V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                        double radius = sp_.r;
+                        if (surely_in || sphere_bbox_hit(cc, radius, r)) {
+                            WORK(++w_prims;)
+                            double t;
+                            if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                                best_t = t;
+                                best_ref = ref;
+                            }
+                        }
+                    }
+                }
+            }
+            cnt = 0u;
+            bf = f32_above(best_t - tsh);
+            if (best_ref != REF_NONE && best_t - tsh <= (double)last_exit) running = false;
+        }
+    }
+
+    // infinite prims last, in order (octree.rs:163-165,185-186)
+    if (active) {
         for (int p = 0; p < sc.n_planes; ++p) {
             const DPlane &pl = sc.planes[p];
             double t;
-            if (MODE == MODE_CLOSEST) {
-                if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
-                    best_t = t;
-                    best_ref = REF_PLANE | p;
-                }
-            } else if (plane_hit(pl, r, t_lo, t_hi, &t)) {
+            if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                best_t = t;
                 best_ref = REF_PLANE | p;
-                break;
             }
         }
     }
     hit->t = best_t;
     hit->ref = best_ref;
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
-    if (MODE == MODE_ANY) *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
 }
 
 template <int MODE>
 DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
-    if (MODE == MODE_CLOSEST || MODE == MODE_ANY) traverse_fast<MODE>(sc, r, s_lds, t_lo, t_hi, hit, prod);
+    // MODE_CLOSEST has its own entry point (traverse_closest_ww: wave-wide flushes, every lane must call it)
+    static_assert(MODE != MODE_CLOSEST, "use traverse_closest_ww");
+    if (MODE == MODE_ANY) traverse_any_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
     else traverse_exact<MODE>(sc, r, s_lds + threadIdx.x, t_lo, t_hi, hit, prod);
 }
 
@@ -890,6 +1060,7 @@ template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
                                                                           DCounters *counters, double *hit_t, int32_t *hit_ref) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : 1];
     init_lds(s_stk);
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
@@ -908,7 +1079,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene
     hit.t = inf();
     hit.ref = REF_NONE;
     WORK(hit.w_nodes = hit.w_entries = hit.w_prims = 0;)
-    if (valid) {
+    if constexpr (MODE == MODE_CLOSEST) {
+        // every lane of the wave takes part in the while-while walk (its flushes are wave-wide)
+        size_t cap = pool.cap;
+        const double *f = pool.f + slot;
+        Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
+                      : make_ray(v3(0, 0, 0), v3(0, 0, 1));
+        traverse_closest_ww(sc, r, valid, s_stk, s_cand, T_MIN, &hit);
+    } else if (valid) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
         Ray r = make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]));
@@ -1309,7 +1487,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         distance_to_light = len(sampled - hp);
     }
 
-    // ---- own ray in f32 (as traverse_fast) for the per-lane primitive box tests
+    // ---- own ray in f32 (as traverse_any_fast) for the per-lane primitive box tests
     const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
     const double tsh = re.t_shift;   // f32 frame re-based to where the ray enters the scene's cube
     const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
@@ -1665,15 +1843,17 @@ template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, const double *origin, const double *direction,
                                                         int32_t *prim_id, double *t_out) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : 1];
     init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (gid >= n) return;
+    if (gid >= n) return;    // lanes that leave here simply drop out of the wave-wide votes below
     V3 o = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
     V3 d = v3(direction[gid * 3], direction[gid * 3 + 1], direction[gid * 3 + 2]);
     Ray r = make_ray(o, d);
     Hit hit;
     V3 unused;
-    traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
+    if constexpr (MODE == MODE_CLOSEST) traverse_closest_ww(sc, r, true, s_stk, s_cand, T_MIN, &hit);
+    else traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     int pid = -1;
     if (hit.ref != REF_NONE) {
         if (hit.ref >= 0 && !(hit.ref & REF_PLANE)) pid = sc.tris[hit.ref].prim_id;

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rtx_device.h"
 
 namespace {
@@ -1588,14 +1590,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     uint32_t tfirst = 0u, tmask = 0u, sp = 0u, qn = 0u;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
 
-    // beam-vs-box test of one child record (see the comment above the beam set-up)
-    auto keep_box = [&](const float4 &qa, const float4 &qb) -> bool {
+    // beam-vs-box test of one child record (see the comment above the beam set-up): c0 = the box along the
+    // group's dominant axis, c1 / c2 = along the other two
+    auto beam_test = [&](float c0l, float c0h, float c1l, float c1h, float c2l, float c2h) -> bool {
         const float *bm = s_beam[sub];
         const float o0min = bm[0], o0max = bm[1], o1min = bm[2], o1max = bm[3], o2min = bm[4], o2max = bm[5];
         const float m1L = bm[6], m1H = bm[7], m2L = bm[8], m2H = bm[9], umax_w = bm[10];
-        const float c0l = a0 == 0 ? qa.x : (a0 == 1 ? qa.y : qa.z), c0h = a0 == 0 ? qa.w : (a0 == 1 ? qb.x : qb.y);
-        const float c1l = a1 == 0 ? qa.x : qa.y, c1h = a1 == 0 ? qa.w : qb.x;
-        const float c2l = a2 == 1 ? qa.y : qa.z, c2h = a2 == 1 ? qb.x : qb.y;
         float u0 = neg0 ? (o0min - c0h) : (c0l - o0max);      // smallest u at which any ray can be inside
         float u1 = neg0 ? (o0max - c0l) : (c0h - o0min);      // largest
         u0 = fmaxf(u0, 0.0f);
@@ -1604,6 +1604,21 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const float b2lo = o2min + fminf(u0 * m2L, u1 * m2L), b2hi = o2max + fmaxf(u0 * m2H, u1 * m2H);
         return u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l;
     };
+    // record = (lo.x, lo.y, lo.z, hi.x | hi.y, hi.z, ref, first_node); AX = dominant axis known at compile time,
+    // -1 = the lane's own a0 (per-lane selects)
+    auto keep_box = [&](auto AX, const float4 &qa, const float4 &qb) -> bool {
+        constexpr int ax = decltype(AX)::value;
+        if constexpr (ax == 0) return beam_test(qa.x, qa.w, qa.y, qb.x, qa.z, qb.y);
+        else if constexpr (ax == 1) return beam_test(qa.y, qb.x, qa.x, qa.w, qa.z, qb.y);
+        else if constexpr (ax == 2) return beam_test(qa.z, qb.y, qa.x, qa.w, qa.y, qb.x);
+        else
+            return beam_test(a0 == 0 ? qa.x : (a0 == 1 ? qa.y : qa.z), a0 == 0 ? qa.w : (a0 == 1 ? qb.x : qb.y),
+                             a1 == 0 ? qa.x : qa.y, a1 == 0 ? qa.w : qb.x, a2 == 1 ? qa.y : qa.z, a2 == 1 ? qb.x : qb.y);
+    };
+    // the four groups of a wave are neighbouring hit points looking at the same light: their dominant axis is
+    // almost always the same, and then a scalar branch picks a beam test without per-lane component selects
+    const int a0_first = __builtin_amdgcn_readfirstlane(a0);
+    const int a0_wave = __all(a0 == a0_first) ? a0_first : -1;
     // the next node of the group's depth-first walk (NONE when the walk is over)
     auto take_node = [&]() -> uint32_t {
         if ((tmask & 0xFFFFu) == 0u && sp > 0u) {   // innermost level exhausted: back to the spilled one (never empty)
@@ -1685,8 +1700,20 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             WORK(w_nodes += hasB ? 2u : 1u;)
             const uint32_t refA = __float_as_uint(a_hi.z), refB = __float_as_uint(b_hi.z);
             const uint32_t kindA = refA & RTX_WREF_KIND, kindB = refB & RTX_WREF_KIND;
-            const bool hitA = keep_box(a_lo, a_hi);             // an empty child's box is (+inf, -inf): never kept
-            const bool hitB = hasB && keep_box(b_lo, b_hi);
+            bool hitA, hitB;                                    // an empty child's box is (+inf, -inf): never kept
+            if (a0_wave == 0) {
+                hitA = keep_box(std::integral_constant<int, 0>(), a_lo, a_hi);
+                hitB = hasB && keep_box(std::integral_constant<int, 0>(), b_lo, b_hi);
+            } else if (a0_wave == 1) {
+                hitA = keep_box(std::integral_constant<int, 1>(), a_lo, a_hi);
+                hitB = hasB && keep_box(std::integral_constant<int, 1>(), b_lo, b_hi);
+            } else if (a0_wave == 2) {
+                hitA = keep_box(std::integral_constant<int, 2>(), a_lo, a_hi);
+                hitB = hasB && keep_box(std::integral_constant<int, 2>(), b_lo, b_hi);
+            } else {
+                hitA = keep_box(std::integral_constant<int, -1>(), a_lo, a_hi);
+                hitB = hasB && keep_box(std::integral_constant<int, -1>(), b_lo, b_hi);
+            }
             const bool isnA = kindA == RTX_WREF_NODE, isnB = kindB == RTX_WREF_NODE;
             const uint32_t hA = (uint32_t)(__ballot(hitA) >> gbase) & 0xFFFFu, kA = (uint32_t)(__ballot(isnA) >> gbase) & 0xFFFFu;
             const uint32_t hB = (uint32_t)(__ballot(hitB) >> gbase) & 0xFFFFu, kB = (uint32_t)(__ballot(isnB) >> gbase) & 0xFFFFu;

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Ray-tree growth of the heptoroid-refractive config (BASELINE config 4) with recursion depth."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("rust-raytracer_amd")
+W, H = int(sys.argv[1]), int(sys.argv[2])
+named = pkg.host.NamedScene("heptoroid-refractive")
+cam = named.camera(W, H, 45.0)
+sc = pkg.Scene(named)
+for depth in [int(a) for a in sys.argv[3:]]:
+    opt = pkg.options(reflect_depth=depth, refract_depth=depth, shadow_samples=1, pixel_samples=1, rng_mode=1, seed=0)
+    t0 = time.time()
+    rgba, ids, st = sc.render(cam, opt, want_ids=False)
+    dt = time.time() - t0
+    print("depth %2d  %dx%d  rays %.4g (%.1f per pixel; refl %.3g refr %.3g shadow %.3g)  %.2f s  %.1f Mrays/s  closest %.0f ms shadow %.0f ms peak pool %d"
+          % (depth, W, H, st.rays_total, st.rays_total / (W * H), st.rays_reflect, st.rays_refract, st.rays_shadow, dt,
+             st.rays_total / dt / 1e6, st.ms_closest, st.ms_shadow, st.peak_pool_rays), flush=True)
+sc.close()

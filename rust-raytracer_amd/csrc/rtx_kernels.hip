@@ -244,9 +244,10 @@ DEV bool plane_hit(const DPlane &pl, const Ray &r, double t_min, double t_max, d
 //                    so exact-t ties between different prims resolve as in ray.rs:52-60.
 // MODE_ANY:          shadow feeler when every material is opaque: stop at the first occluder
 //                    inside [EPSILON, dist] (the product would be exactly 0 from there on).
+// MODE_PRODUCT_FAST: the same multiset as MODE_PRODUCT, boxes classified in f32 (traverse_product_fast).
 // MODE_PRODUCT:      shadow feeler with transmissive materials: every candidate of the
 //                    multiset, duplicates included (renderer.rs:209-217), order-free product.
-enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3 };
+enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4 };
 
 struct Hit {
     double t;
@@ -616,6 +617,177 @@ DEV void traverse_any_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, doub
     *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
 }
 
+// Shadow PRODUCT over the reference's exact candidate multiset (scenes with transmissive materials,
+// renderer.rs:209-217), at f32 speed.  The product needs every primitive once per leaf that the reference's
+// walk reaches and that lists it, so the walk must visit EXACTLY the nodes whose boxes pass BBox::intersects in
+// f64 (bbox.rs:99-165: no ray range, only "in front of the origin") — no culling by distance, no mailbox.
+// Each child box is classified in f32:  the box widened by delta missed => the f64 test fails;  the box shrunk
+// by delta passed (cross-axis form, surely_hit) => the f64 test passes;  the few in between (a ray within delta
+// of a face or an edge, or an axis-parallel ray) are decided by the f64 test itself, with the child box computed
+// by the reference's own expressions (octree.rs:79-92).  Leaf entries go the same way (f32 reject, surely-in, or
+// the exact entry-bbox test), then the exact primitive test.  traverse_exact<MODE_PRODUCT> remains as the
+// all-f64 restatement (rtx_shadow_products, RTX_FLAG_REFERENCE_ORDER) the tests compare this walk with.
+DEV bool surely_hit(float nx, float ny, float nz, float fx, float fy, float fz) {
+    // n*: upper bounds of the near slab distances, f*: lower bounds of the far ones.  BBox::intersects passes iff every
+    // cross-axis pair is ordered and the smallest far distance is > 0 (an axis is never compared with itself).
+    return nx <= fminf(fy, fz) && ny <= fminf(fx, fz) && nz <= fminf(fx, fy) && fminf(fminf(fx, fy), fz) > 0.0f;
+}
+DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
+    uint32_t *stk = s_lds + threadIdx.x;   // level stack, stride RTX_BLOCK
+    const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
+    V3 acc = v3(1.0, 1.0, 1.0);            // shadow product (renderer.rs:211)
+    bool done = false;     // the walk is over
+    bool zero = false;     // the product has reached exactly (0,0,0): nothing can change it any more
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
+
+    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh; tsh >= 0, so "t > 0" holds whenever "t - tsh > 0"
+    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
+    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+    const double delta = big * (1.0 / 1048576.0);
+    const bool sx = r.sx, sy = r.sy, sz = r.sz;
+    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
+    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
+    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
+    const uint32_t flip = r.flip;
+    const uint8_t *perm_row = perm + (flip << 8);
+    // the f32 frame starts where the ray enters the scene's cube: a box "in front of the origin" in the reference's
+    // sense may lie behind that point only if the origin is inside the cube, where tsh = 0
+    const float front = 0.0f;
+
+    int sp = 0;
+    uint32_t cur = 0;
+    bool have_cur = true;           // root: never tested (octree.rs:149,177)
+    if (re.miss) done = true;       // the ray misses the cube that holds every finite prim: no box inside it passes
+    while (!done) {
+        if (!have_cur) {
+            while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
+            if (sp == 0) break;
+            uint32_t e = stk[(sp - 1) * RTX_BLOCK];
+            uint32_t j = (uint32_t)__ffs((int)(e & 0xFFu)) - 1u;
+            stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
+            cur = (e >> 8) + (j ^ flip);
+        }
+        have_cur = false;
+        const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
+        const float4 qa = nq[0], qb = nq[1];
+        const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
+        const uint32_t link = __float_as_uint(qb.z), aux = __float_as_uint(qb.w);
+        WORK(++w_nodes;)
+        if (aux == 0xFFFFFFFFu) {
+            const float pnx = sx ? minx : maxx, pfx = sx ? maxx : minx;
+            const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
+            const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
+            const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
+            // per axis: near half = [p_near, mid], far half = [mid, p_far]; W = widened (cn on entries, cf on exits),
+            // S = shrunk (cf on entries, cn on exits)
+            const float wn0x = fmaf(pnx, ix, cnx), wn1x = fmaf(mx, ix, cnx), wf0x = fmaf(mx, ix, cfx), wf1x = fmaf(pfx, ix, cfx);
+            const float wn0y = fmaf(pny, iy, cny), wn1y = fmaf(my, iy, cny), wf0y = fmaf(my, iy, cfy), wf1y = fmaf(pfy, iy, cfy);
+            const float wn0z = fmaf(pnz, iz, cnz), wn1z = fmaf(mz, iz, cnz), wf0z = fmaf(mz, iz, cfz), wf1z = fmaf(pfz, iz, cfz);
+            const float sn0x = fmaf(pnx, ix, cfx), sn1x = fmaf(mx, ix, cfx), sf0x = fmaf(mx, ix, cnx), sf1x = fmaf(pfx, ix, cnx);
+            const float sn0y = fmaf(pny, iy, cfy), sn1y = fmaf(my, iy, cfy), sf0y = fmaf(my, iy, cny), sf1y = fmaf(pfy, iy, cny);
+            const float sn0z = fmaf(pnz, iz, cfz), sn1z = fmaf(mz, iz, cfz), sf0z = fmaf(mz, iz, cnz), sf1z = fmaf(pfz, iz, cnz);
+            uint32_t maybe = 0, sure = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const float lo = fmaxf(fmaxf(fmaxf((j & 4u) ? wn1x : wn0x, front), (j & 2u) ? wn1y : wn0y), (j & 1u) ? wn1z : wn0z);
+                const float hi = fminf(fminf((j & 4u) ? wf1x : wf0x, (j & 2u) ? wf1y : wf0y), (j & 1u) ? wf1z : wf0z);
+                maybe |= (lo <= hi) ? (1u << j) : 0u;
+                const bool s_ = surely_hit((j & 4u) ? sn1x : sn0x, (j & 2u) ? sn1y : sn0y, (j & 1u) ? sn1z : sn0z,
+                                           (j & 4u) ? sf1x : sf0x, (j & 2u) ? sf1y : sf0y, (j & 1u) ? sf1z : sf0z);
+                sure |= s_ ? (1u << j) : 0u;
+            }
+            const uint32_t present = (uint32_t)perm_row[link & 0xFFu];   // children whose subtree holds an entry, in near-to-far bit order
+            if (!finite_dir) { maybe = 0xFFu; sure = 0u; }               // NaNs (0 * inf) in the f32 distances: let the f64 test decide
+            uint32_t pending = sure & present;
+            uint32_t border = maybe & ~sure & present;
+            if (border) {
+                // the reference's own child boxes and test (octree.rs:79-92, bbox.rs:99-165) for the undecided children
+                const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + cur);
+                const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                const double bminx = q0.x, bminy = q0.y, bminz = q1.x, bmaxx = q1.y, bmaxy = q2.x, bmaxz = q2.y;
+                const double hlx = (bmaxx - bminx) / 2.0, hly = (bmaxy - bminy) / 2.0, hlz = (bmaxz - bminz) / 2.0;
+                while (border) {
+                    const uint32_t j = (uint32_t)__ffs((int)border) - 1u;
+                    border &= border - 1u;
+                    const uint32_t k = j ^ flip;   // child index x*4 + y*2 + z
+                    const double cminx = (k & 4u) ? bminx + hlx : bminx, cmaxx = (k & 4u) ? bmaxx : bmaxx - hlx;
+                    const double cminy = (k & 2u) ? bminy + hly : bminy, cmaxy = (k & 2u) ? bmaxy : bmaxy - hly;
+                    const double cminz = (k & 1u) ? bminz + hlz : bminz, cmaxz = (k & 1u) ? bmaxz : bmaxz - hlz;
+                    double tn, tf;
+                    if (slab(cminx, cminy, cminz, cmaxx, cmaxy, cmaxz, r, &tn, &tf)) pending |= 1u << j;
+                }
+            }
+            if (pending) {
+                stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
+                ++sp;
+            }
+        } else {
+            const DEntry32 *ep = sc.entries32 + link;
+            for (uint32_t e = 0; e < aux && !zero; ++e) {
+                const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
+                const float4 ea = eq[0], eb = eq[1];
+                WORK(++w_entries;)
+                const float enx = sx ? ea.x : ea.w, efx = sx ? ea.w : ea.x;
+                const float eny = sy ? ea.y : eb.x, efy = sy ? eb.x : ea.y;
+                const float enz = sz ? ea.z : eb.y, efz = sz ? eb.y : ea.z;
+                bool surely_in = false;
+                if (finite_dir) {
+                    // widened entry box missed => the exact entry-bbox test (octree.rs:170) fails
+                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), front), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
+                    const float hi = fminf(fminf(fmaf(efx, ix, cfx), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
+                    if (!(lo <= hi)) continue;
+                    surely_in = surely_hit(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy), fmaf(enz, iz, cfz), fmaf(efx, ix, cnx), fmaf(efy, iy, cny),
+                                           fmaf(efz, iz, cnz));
+                }
+                const int ref = __float_as_int(eb.z);
+                int mat;
+                bool occl = false;
+                if (ref >= 0) {
+                    int pid;
+                    TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                    if (!surely_in && !tri_bbox_hit(tr, r)) continue;
+                    WORK(++w_prims;)
+                    double t, be, ga;
+                    occl = tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga);
+                } else {
+                    const DSphere &sp_ = sc.spheres[~ref];
+                    V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                    mat = sp_.material;
+                    if (!surely_in && !sphere_bbox_hit(c, sp_.r, r)) continue;
+                    WORK(++w_prims;)
+                    double t;
+                    occl = sphere_hit(c, sp_.r, r, t_lo, t_hi, &t);
+                }
+                if (occl) {
+                    const rtx_material &m = sc.materials[mat];
+                    if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                    else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                    if (acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0) { zero = true; done = true; }   // finite factors: it stays exactly 0
+                }
+            }
+        }
+    }
+    // infinite prims last, in order (octree.rs:163-165,185-186)
+    if (!zero) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            const DPlane &pl = sc.planes[p];
+            double t;
+            if (plane_hit(pl, r, t_lo, t_hi, &t)) {
+                const rtx_material &m = sc.materials[pl.material];
+                if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+            }
+        }
+    }
+    hit->t = t_hi;
+    hit->ref = REF_NONE;
+    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
+    *prod = acc;
+}
+
 // Closest hit as a WHILE-WHILE walk with DEFERRED exact tests (k_closest, k_nearest).  Same nodes, same
 // conservative f32 tests and same exact f64 tests as the per-lane any-hit walk above, arranged so that the lanes of
 // a wave do the same kind of work at the same time:
@@ -830,7 +1002,8 @@ template <int MODE>
 DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
     // MODE_CLOSEST has its own entry point (traverse_closest_ww: wave-wide flushes, every lane must call it)
     static_assert(MODE != MODE_CLOSEST, "use traverse_closest_ww");
-    if (MODE == MODE_ANY) traverse_any_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
+    if constexpr (MODE == MODE_ANY) traverse_any_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
+    else if constexpr (MODE == MODE_PRODUCT_FAST) traverse_product_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
     else traverse_exact<MODE>(sc, r, s_lds + threadIdx.x, t_lo, t_hi, hit, prod);
 }
 
@@ -1942,8 +2115,11 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     else if (sc.all_opaque)
         hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
-    else
+    else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+    else
+        hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_FAST>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
 }
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out) {

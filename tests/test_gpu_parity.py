@@ -322,3 +322,28 @@ def test_registry_scenes_parity(rtx, orc, name, fov):
     sc.close()
     _compare(rgba, ids, orgba, oids)
     assert abs(int(st.rays_total) - int(ocn.rays_total)) <= 1e-3 * ocn.rays_total + 2
+
+
+@pytest.mark.parametrize("which", ["mesh_transmissive", "cornell", "kitchen"])
+def test_fast_shadow_product_equals_exact_walk(rtx, orc, which):
+    """Scenes with transmissive materials: the f32-classified walk (traverse_product_fast) must reach exactly the
+    reference's candidate multiset, i.e. give the images of the all-f64 restatement (RTX_FLAG_REFERENCE_ORDER),
+    for soft coloured shadows through up to several transmissive layers, and both must match the oracle."""
+    if which == "kitchen":
+        flat, cam_fn = scenes.kitchen_sink_scene(rtx)
+    elif which == "cornell":
+        flat, cam_fn = scenes.cornell_scene(rtx)
+    else:
+        flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=True)
+    cam = cam_fn(144, 96)
+    kw = dict(reflect_depth=4, refract_depth=4, shadow_samples=8, pixel_samples=2, rng_mode=1, seed=21)
+    sc = rtx.Scene(flat)
+    assert sc.info().all_opaque == 0
+    a, ia, sa = sc.render(cam, rtx.options(**kw))
+    b, ib, sb = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_REFERENCE_ORDER, **kw))
+    sc.close()
+    assert (ia == ib).mean() >= 0.9999
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3   # up to the order of f64 atomic adds
+    assert sa.rays_total == sb.rays_total
+    orgba, oids, _ = orc.Scene(flat).render(cam, rtx.options(**kw), threads=16)
+    _compare(a, ia, orgba, oids, rgb_bar=0.995)

@@ -198,19 +198,26 @@ def main():
             avg_ms = ms / max(1.0, launches)
             achieved = bpr * (nrays / max(1.0, launches)) / (avg_ms * 1e-3) / 1e9
             traffic = None
-            try:   # HBM bytes per launch of that kernel from separate rocprofv3 --pmc passes (profiles/)
+            pmc = {}
+            try:   # HBM bytes per launch of that kernel + SQ counters from separate rocprofv3 --pmc passes (profiles/)
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                    traffic = json.load(fh).get(args.workload, {}).get(kname)
+                    pmc = json.load(fh).get(args.workload, {})
+                    traffic = pmc.get(kname)
             except (OSError, ValueError):
                 pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                                "avg_launch_ms": avg_ms, "launches_per_frame": launches,
                                "algorithmic_bytes_per_ray": bpr, "rays_per_launch": nrays / max(1.0, launches),
+                               # what the kernel physically does (profiles/): HBM rate = measured bytes per launch / live launch time;
+                               # VALU figures from the SQ counter pass of the same command
+                               "hbm_measured_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                               "valu": pmc.get(kname + "_valu"),
                                "note": "achieved uses the REFERENCE-ORDER algorithmic bytes SURVEY.md 8d defines (oracle traversal "
                                        "counters: every pierced leaf, no early-out), which the GPU kernels avoid touching by ordered, "
                                        "culled, cooperative traversal, so frac > 1 is expected; traffic = measured HBM bytes per launch "
-                                       "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes, profiles/)"}
+                                       "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes, profiles/); the kernel is "
+                                       "VALU-issue bound on cache-resident data (valu.busy), not HBM bound (hbm_measured_gbs vs peak)"}
         print(json.dumps(out), flush=True)
 
     scene.close()

@@ -791,7 +791,7 @@ DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, 
 // Closest hit as a WHILE-WHILE walk with DEFERRED exact tests (k_closest, k_nearest).  Same nodes, same
 // conservative f32 tests and same exact f64 tests as the per-lane any-hit walk above, arranged so that the lanes of
 // a wave do the same kind of work at the same time:
-//   phase 1  every lane descends the octree until it stands in a leaf (or its walk is over);
+//   phase 1  every lane descends the octree towards its next leaf (a bounded number of nodes per round);
 //   phase 2  every lane scans its leaf's entries; a candidate that passes the f32 entry test is PARKED in a
 //            small per-lane LDS buffer instead of being tested on the spot;
 //   phase 3  when a buffer is full, enough lanes hold candidates or nobody walks any more, the wave tests the
@@ -808,6 +808,9 @@ DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, 
 #define RTX_DEFER_FLUSH 24    // flush once this many lanes hold parked candidates
 #endif
 #define RTX_CAND_WORDS (RTX_DEFER_CAP * RTX_BLOCK)
+#ifndef RTX_DESCENT_STEPS
+#define RTX_DESCENT_STEPS 4   // nodes a lane may visit per round before the wave moves on to the entry scans
+#endif
 #ifndef RTX_ENTRY_BATCH
 #define RTX_ENTRY_BATCH 4     // leaf entries fetched together
 #endif
@@ -845,8 +848,10 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
 
     for (;;) {
         if (!__any(running || cnt > 0u)) break;
-        // ---- phase 1: descend until the lane stands in a non-empty leaf or its walk is over
-        while (running && e_cur >= e_end) {
+        // ---- phase 1: descend towards the next non-empty leaf, at most RTX_DESCENT_STEPS nodes per round: descents differ
+        // in length by 3x between the lanes of a wave (culled nodes, depth), and lanes that already stand in a leaf
+        // must not wait for the longest one (uncapped: 80 -> capped at 4: 65 ms per sponza frame)
+        for (int step = 0; step < RTX_DESCENT_STEPS && running && e_cur >= e_end; ++step) {
             uint32_t cur = 0;
             if (!at_root) {
                 while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
@@ -941,7 +946,7 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
         }
         if (running && e_cur >= e_end) last_exit = cur_exit;   // leaf completed
         // ---- phase 3: flush
-        const bool stalled = running && e_cur < e_end;   // buffer full in mid-leaf
+        const bool stalled = running && e_cur < e_end && cnt >= RTX_DEFER_CAP;   // buffer full in mid-leaf
         const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
         if (__any(stalled) || holders >= RTX_DEFER_FLUSH || !__any(running)) {
             for (uint32_t i = 0; __any(i < cnt); ++i) {

@@ -166,7 +166,7 @@ def main():
                 "shadow": dict(zip(("nodes", "leaf_entries", "prim_tests"), [w / max(1, r0.rays_shadow) for w in wk[1]]))}
 
         cpu = None
-        if args.cpu_blocks > 0:
+        if args.cpu_blocks > 0 and world == 1:   # the CPU baseline (and the roofline built on its counters) is an N=1 figure
             orc = importlib.import_module("oracle.oracle")   # the checker + CPU baseline, never the product
             threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             oscene = orc.Scene(named)

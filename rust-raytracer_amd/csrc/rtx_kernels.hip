@@ -1614,6 +1614,15 @@ DEV float grp_max(float v) {
         : "v"(v));
     return a;
 }
+// MULTI = false: the 16 lanes of a group are feelers of ONE hit point (tries a multiple of 16).
+// MULTI = true:  tries is 4 or 8 and a group holds the feelers of 16 / tries neighbouring hit points.  Such a
+//                group is walked only if its hit points lie close together (RTX_COOP_WIDE); the others (a ground
+//                plane seen near the horizon, a silhouette) are left in the queue for the per-lane kernel that
+//                runs next, and every queue entry this kernel has finished is marked empty.
+#ifndef RTX_COOP_WIDE
+#define RTX_COOP_WIDE 0.02f   // largest spread of a group's hit points, as a fraction of the scene's radius
+#endif
+template <bool MULTI>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
                                                                             uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
                                                                             DCounters *counters, double *acc) {
@@ -1628,7 +1637,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     __shared__ uint32_t s_hit[RTX_BLOCK];
     // every lane's feeler (origin, direction, inverse direction), read back by the lane that runs its exact tests
     __shared__ double s_ray[6][RTX_BLOCK];      // direction, inverse direction per lane
-    __shared__ double s_org[3][RTX_BLOCK / 16]; // origin: one hit point per group (tries is a multiple of 16)
+    __shared__ double s_org[3][MULTI ? RTX_BLOCK : RTX_BLOCK / 16];   // origin: per group (one hit point), or per lane
     // each group's beam (11 floats), re-read at every node step: they would otherwise sit in registers during the
     // exact tests, where the pressure peaks, and be spilled to scratch memory
     __shared__ float s_beam[RTX_BLOCK / 16][12];
@@ -1725,6 +1734,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     grp_min_max(walk ? f32_below(o0) : INF, walk ? f32_above(o0) : -INF, &o0min, &o0max);
     grp_min_max(walk ? f32_below(o1) : INF, walk ? f32_above(o1) : -INF, &o1min, &o1max);
     grp_min_max(walk ? f32_below(o2) : INF, walk ? f32_above(o2) : -INF, &o2min, &o2max);
+    // MULTI: a group whose hit points are spread out (or whose feelers point in mixed directions) makes a beam that
+    // touches much of the hierarchy: it is left to the per-lane kernel.  Group-uniform (from the reductions).
+    bool wide = false;
+    if (MULTI) {
+        const float spread = fmaxf(fmaxf(o0max - o0min, o1max - o1min), o2max - o2min);   // NaN / -inf (no walker): not wide
+        wide = !beam_ok || spread > RTX_COOP_WIDE * (float)sc.radius;
+    }
     const double inv0 = 1.0 / fabs(d0);
     grp_min_max(walk ? f32_below(d1 * inv0) : INF, walk ? f32_above(d1 * inv0) : -INF, &m1L, &m1H);
     grp_min_max(walk ? f32_below(d2 * inv0) : INF, walk ? f32_above(d2 * inv0) : -INF, &m2L, &m2H);
@@ -1759,7 +1775,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     const uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t below = (1u << l16) - 1u;
     bool alive = valid;     // the feeler has met no occluder yet
-    bool seek = walk;       // ... and can still meet a finite one
+    bool seek = walk && !wide;   // ... and can still meet a finite one (a wide group does not walk at all)
     uint32_t a16 = (uint32_t)(__ballot(seek) >> gbase) & 0xFFFFu;
     // Group state, replicated in every lane of the group (it is computed from ballots only).
     // A LEVEL is a visited node with node-children still to visit: (tfirst, tmask) is the innermost
@@ -1817,7 +1833,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     const uint32_t wid = threadIdx.x >> 6;
     uint32_t pair_n = 0u;           // wave-uniform
     s_hit[threadIdx.x] = 0u;
-    if (l16 == 0u) { s_org[0][sub] = r.ox; s_org[1][sub] = r.oy; s_org[2][sub] = r.oz; }
+    if (MULTI) { s_org[0][threadIdx.x] = r.ox; s_org[1][threadIdx.x] = r.oy; s_org[2][threadIdx.x] = r.oz; }
+    else if (l16 == 0u) { s_org[0][sub] = r.ox; s_org[1][sub] = r.oy; s_org[2][sub] = r.oz; }
     s_ray[0][threadIdx.x] = r.dx; s_ray[1][threadIdx.x] = r.dy; s_ray[2][threadIdx.x] = r.dz;
     s_ray[3][threadIdx.x] = r.ix; s_ray[4][threadIdx.x] = r.iy; s_ray[5][threadIdx.x] = r.iz;
     COOP_FENCE();
@@ -1830,7 +1847,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const double q_dist = __shfl(distance_to_light, (int)(pr.y & 63u));
         if (mine && s_hit[owner] == 0u) {
             Ray q;
-            q.ox = s_org[0][owner >> 4]; q.oy = s_org[1][owner >> 4]; q.oz = s_org[2][owner >> 4];
+            const uint32_t oi = MULTI ? owner : (owner >> 4);
+            q.ox = s_org[0][oi]; q.oy = s_org[1][oi]; q.oz = s_org[2][oi];
             q.dx = s_ray[0][owner]; q.dy = s_ray[1][owner]; q.dz = s_ray[2][owner];
             q.ix = q.iy = q.iz = 0.0; q.sx = q.sy = q.sz = true; q.flip = 0u;   // read by the entry-bbox tests only
             // the inverse direction is fetched only where the exact entry-bbox test runs (keeps the primitive
@@ -1977,9 +1995,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
 
     while (pair_n > 0u) run_pairs();   // what the last drains left waiting (RTX_COOP_PT > 1 only)
     // infinite prims (planes), octree.rs:163-165: a feeler that is still clear tests them in order
-    if (alive) {
+    if (alive && !wide) {
         Ray q;      // the lane's own feeler again (kept in LDS, not in registers, during the walk)
-        q.ox = s_org[0][sub]; q.oy = s_org[1][sub]; q.oz = s_org[2][sub];
+        const uint32_t oi = MULTI ? threadIdx.x : sub;
+        q.ox = s_org[0][oi]; q.oy = s_org[1][oi]; q.oz = s_org[2][oi];
         q.dx = s_ray[0][threadIdx.x]; q.dy = s_ray[1][threadIdx.x]; q.dz = s_ray[2][threadIdx.x];
         for (int p = 0; p < sc.n_planes; ++p) {
             double t;
@@ -2007,10 +2026,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     uint32_t t2 = threadIdx.x;
     asm volatile("" : "+v"(t2));   // group / try index and loads afresh, not the prologue's values kept alive
     const uint64_t gid2 = (uint64_t)blockIdx.x * RTX_BLOCK + t2;
-    if (valid && (gid2 % tries == 0u || !pow2_tries)) {
+    if (valid && !wide && (gid2 % tries == 0u || !pow2_tries)) {
         const uint32_t g2 = (uint32_t)(gid2 / tries);
         const double *f = sq.f + (size_t)light * 6 * qc + g2;
         acc_add(acc, sq.sample[(size_t)light * qc + g2], v3(f[3 * qc], f[4 * qc], f[5 * qc]) * scale(v, inv_tries));   // renderer.rs:220,118
+        if (MULTI) sq.sample[(size_t)light * qc + g2] = SHADOW_GROUP_EMPTY;   // done: the per-lane pass that follows skips it
     }
 }
 
@@ -2113,11 +2133,18 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
     // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
     // wide (a ground plane seen near the horizon) and walk most of the hierarchy
-    const bool single_origin = tries % 16u == 0u;   // k_shadow_coop relies on it (one origin per group in LDS)
-    if (sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && single_origin)
-        hipLaunchKernelGGL(k_shadow_coop, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, n_groups,
-                           tries, pow2, counters, acc);
-    else if (sc.all_opaque)
+    const bool coop = sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP);
+    if (coop && tries % 16u == 0u) {        // the 16 lanes of a group = feelers of one hit point
+        hipLaunchKernelGGL(k_shadow_coop<false>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+    } else if (coop && (tries == 4u || tries == 8u)) {   // measured: with 1 try per hit point (16 origins per group) the per-lane walk wins
+        // groups of 16 / tries neighbouring hit points: the cooperative kernel takes the compact ones and marks their
+        // queue entries empty, the per-lane kernel takes what is left
+        hipLaunchKernelGGL(k_shadow_coop<true>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+        hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+    } else if (sc.all_opaque)
         hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk

@@ -223,11 +223,12 @@ def test_bad_arguments(rtx):
     sc.close()
 
 
-@pytest.mark.parametrize("tries", [1, 2, 4, 16, 3])
+@pytest.mark.parametrize("tries", [1, 2, 4, 8, 16, 32, 3])
 def test_cooperative_shadows_equal_per_lane_shadows(rtx, tries):
     """The cooperative 16-lane box-list traversal and the per-lane octree walk are two exact any-hit
-    searches over the same primitives: for every group size (also a non-power-of-two sample count)
-    the images must be identical."""
+    searches over the same primitives: for every group size the images must be identical.  16 and 32 tries:
+    one hit point per group; 4 and 8: groups of neighbouring hit points, the compact ones walked cooperatively
+    and the rest left to the per-lane kernel; 1, 2 and 3 (not a power of two): per-lane only."""
     flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32)
     cam = cam_fn(160, 96)
     sc = rtx.Scene(flat)

@@ -424,7 +424,7 @@ DEV void traverse_exact(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, st
     else *prod = acc;
 }
 
-// Fast traversals (closest hit: traverse_closest_ww, any hit: traverse_any_fast and k_shadow_coop).  Node and leaf-entry boxes are tested in f32
+// Fast traversals (closest hit and per-lane any hit: traverse_ww, cooperative any hit: k_shadow_coop, shadow product: traverse_product_fast).  Node and leaf-entry boxes are tested in f32
 // against the outward-rounded DNode32 / DEntry32 twins, widened by a per-ray delta that bounds
 // every rounding error of the f32 arithmetic (origin and inverse direction rounded to f32, one
 // subtraction and one multiplication per plane: < 2^-22 * S in position units, S = largest
@@ -481,142 +481,6 @@ DEV void init_lds(uint32_t *s_lds) {
     }
     __syncthreads();
 }
-// Any-hit walk of one shadow feeler per lane over the octree (k_shadow<MODE_ANY>: all-opaque scenes whose
-// feeler groups the cooperative kernel does not take): stop at the first occluder inside [t_lo, t_hi].
-DEV void traverse_any_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
-    uint32_t *stk = s_lds + threadIdx.x;   // level stack, stride RTX_BLOCK
-    const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
-    int best_ref = REF_NONE;
-    bool done = false;
-    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
-
-    // The ray in f32 relative to the root centre: slab distance of plane p = fma(p, i, c) with
-    // c = -o*i.  The widening by delta is folded into c: cn (near planes, delta towards the
-    // origin side) and cf (far planes, delta away), h = delta * |i|.
-    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
-    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh
-    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
-    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
-    const double delta = big * (1.0 / 1048576.0);
-    const bool sx = r.sx, sy = r.sy, sz = r.sz;
-    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
-    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
-    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
-    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
-    // axis-parallel rays put NaNs (0 * inf) into the slab distances; max3/min3 drop them, which
-    // only weakens a cull, but the "surely inside" shortcut below must not be taken then
-    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
-    const uint32_t flip = r.flip;
-    const uint8_t *perm_row = perm + (flip << 8);
-    const float bf = f32_above(t_hi - tsh);   // upper bound of the feeler's length (shifted) for the f32 culls
-    int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
-
-    int sp = 0;
-    uint32_t cur = 0;
-    bool have_cur = true;           // root: never culled (octree.rs:149,177)
-    if (re.miss) done = true;       // the ray misses the cube that holds every finite prim
-    const bool skip_finite = re.miss;
-    while (!done) {
-        if (!have_cur) {
-            while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
-            if (sp == 0) break;
-            uint32_t e = stk[(sp - 1) * RTX_BLOCK];
-            uint32_t j = (uint32_t)__ffs((int)(e & 0xFFu)) - 1u;
-            stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
-            cur = (e >> 8) + (j ^ flip);
-        }
-        have_cur = false;
-        const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
-        const float4 qa = nq[0], qb = nq[1];
-        const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
-        const uint32_t link = __float_as_uint(qb.z), aux = __float_as_uint(qb.w);
-        WORK(++w_nodes;)
-        const float pnx = sx ? minx : maxx, pfx = sx ? maxx : minx;
-        const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
-        const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
-        const float t0x = fmaf(pnx, ix, cnx), t0y = fmaf(pny, iy, cny), t0z = fmaf(pnz, iz, cnz);
-
-        if (aux == 0xFFFFFFFFu) {
-            // child boxes = halves of this box (octree.rs:79-92); the f64 mid planes max - len/2 and
-            // min + len/2 differ from 0.5*(min+max) by rounding only, far inside delta
-            const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
-            // x carries the clamps: entry >= 0 and exit <= bf, so one compare decides a child
-            const float n0x = fmaxf(t0x, 0.0f), n1x = fmaxf(fmaf(mx, ix, cnx), 0.0f);   // near half / far half entry
-            const float f0x = fminf(fmaf(mx, ix, cfx), bf), f1x = fminf(fmaf(pfx, ix, cfx), bf);
-            const float n0y = t0y, n1y = fmaf(my, iy, cny), f0y = fmaf(my, iy, cfy), f1y = fmaf(pfy, iy, cfy);
-            const float n0z = t0z, n1z = fmaf(mz, iz, cnz), f0z = fmaf(mz, iz, cfz), f1z = fmaf(pfz, iz, cfz);
-            uint32_t pending = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) {
-                float lo = fmaxf(fmaxf((j & 4u) ? n1x : n0x, (j & 2u) ? n1y : n0y), (j & 1u) ? n1z : n0z);
-                float hi = fminf(fminf((j & 4u) ? f1x : f0x, (j & 2u) ? f1y : f0y), (j & 1u) ? f1z : f0z);
-                pending |= (lo <= hi) ? (1u << j) : 0u;
-            }
-            pending &= (uint32_t)perm_row[link & 0xFFu];
-            if (pending) {
-                stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
-                ++sp;
-            }
-        } else {
-            const DEntry32 *ep = sc.entries32 + link;
-            for (uint32_t e = 0; e < aux; ++e) {
-                const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
-                const float4 ea = eq[0], eb = eq[1];
-                WORK(++w_entries;)
-                // conservative f32 version of the entry's own bbox test (octree.rs:170)
-                const float enx = sx ? ea.x : ea.w, efx = sx ? ea.w : ea.x;
-                const float eny = sy ? ea.y : eb.x, efy = sy ? eb.x : ea.y;
-                const float enz = sz ? ea.z : eb.y, efz = sz ? eb.y : ea.z;
-                {
-                    float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
-                    float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), bf), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
-                    if (!(lo <= hi)) continue;
-                }
-                const int ref = __float_as_int(eb.z);
-                if (ref == last_ref0 || ref == last_ref1) continue;   // already tested with the same window
-                last_ref1 = last_ref0;
-                last_ref0 = ref;
-                // the box shrunk by delta instead of widened: a ray through it passes the exact f64
-                // entry test with a margin far above f64 rounding, so that test can be skipped
-                bool surely_in = false;
-                if (finite_dir) {
-                    float lo = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
-                    float hi = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
-                    surely_in = lo <= hi && hi > 0.0f;
-                }
-                if (ref >= 0) {
-                    int pid, mat;
-                    TriV tr = load_tri(sc.tris, ref, &pid, &mat);
-                    if (!surely_in && !tri_bbox_hit(tr, r)) continue;
-                    WORK(++w_prims;)
-                    double t, be, ga;
-                    if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) { best_ref = ref; done = true; break; }
-                } else {
-                    const DSphere &sp_ = sc.spheres[~ref];
-                    V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
-                    double radius = sp_.r;
-                    if (!surely_in && !sphere_bbox_hit(c, radius, r)) continue;
-                    WORK(++w_prims;)
-                    double t;
-                    if (sphere_hit(c, radius, r, t_lo, t_hi, &t)) { best_ref = ref; done = true; break; }
-                }
-            }
-        }
-    }
-
-    // infinite prims last, in order (octree.rs:163-165,185-186)
-    if (!(done && !skip_finite)) {
-        for (int p = 0; p < sc.n_planes; ++p) {
-            double t;
-            if (plane_hit(sc.planes[p], r, t_lo, t_hi, &t)) { best_ref = REF_PLANE | p; break; }
-        }
-    }
-    hit->t = t_hi;
-    hit->ref = best_ref;
-    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
-    *prod = (best_ref == REF_NONE) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
-}
-
 // Shadow PRODUCT over the reference's exact candidate multiset (scenes with transmissive materials,
 // renderer.rs:209-217), at f32 speed.  The product needs every primitive once per leaf that the reference's
 // walk reaches and that lists it, so the walk must visit EXACTLY the nodes whose boxes pass BBox::intersects in
@@ -789,7 +653,7 @@ DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, 
 }
 
 // Closest hit as a WHILE-WHILE walk with DEFERRED exact tests (k_closest, k_nearest).  Same nodes, same
-// conservative f32 tests and same exact f64 tests as the per-lane any-hit walk above, arranged so that the lanes of
+// conservative f32 tests and same exact f64 tests as the reference's walk, arranged so that the lanes of
 // a wave do the same kind of work at the same time:
 //   phase 1  every lane descends the octree towards its next leaf (a bounded number of nodes per round);
 //   phase 2  every lane scans its leaf's entries; a candidate that passes the f32 entry test is PARKED in a
@@ -814,11 +678,14 @@ DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, 
 #ifndef RTX_ENTRY_BATCH
 #define RTX_ENTRY_BATCH 4     // leaf entries fetched together
 #endif
-DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, Hit *hit) {
+// ANY = true: the any-hit search of a shadow feeler (k_shadow<MODE_ANY>): the window is [t_lo, t_hi] for every candidate and
+// the lane stops at the first flush that finds an occluder.
+template <bool ANY>
+DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit) {
     uint32_t *stk = s_lds + threadIdx.x;     // level stack, stride RTX_BLOCK
     uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
     const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
-    double best_t = inf();
+    double best_t = ANY ? t_hi : inf();   // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
     int best_ref = REF_NONE;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
 
@@ -875,7 +742,8 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
             if (culled) continue;
             WORK(++w_nodes;)
             if (aux == 0xFFFFFFFFu) {
-                // child boxes = halves of this box (octree.rs:79-92), see traverse_any_fast
+                // child boxes = halves of this box (octree.rs:79-92); the f64 mid planes max - len/2 and min + len/2 differ from
+                // 0.5*(min+max) by rounding only, far inside delta.  x carries the clamps (entry >= 0, exit <= bf)
                 const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
                 const float n0x = fmaxf(t0x, 0.0f), n1x = fmaxf(fmaf(mx, ix, cnx), 0.0f);
                 const float f0x = fminf(fmaf(mx, ix, cfx), bf), f1x = fminf(fmaf(pfx, ix, cfx), bf);
@@ -950,7 +818,7 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
         const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
         if (__any(stalled) || holders >= RTX_DEFER_FLUSH || !__any(running)) {
             for (uint32_t i = 0; __any(i < cnt); ++i) {
-                if (i < cnt) {
+                if (i < cnt && !(ANY && best_ref != REF_NONE)) {   // any-hit: one occluder is enough
                     const uint32_t c = cand[i * RTX_BLOCK];
                     const int ref = (int)c >> 1;
                     const bool surely_in = (c & 1u) != 0u;
@@ -960,8 +828,10 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
                         if (surely_in || tri_bbox_hit(tr, r)) {
                             WORK(++w_prims;)
                             double t, be, ga;
-                            // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
-                            if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                            if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
+                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
+                            } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                                // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
                                 best_t = t;
                                 best_ref = ref;
                             }
@@ -973,7 +843,9 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
                         if (surely_in || sphere_bbox_hit(cc, radius, r)) {
                             WORK(++w_prims;)
                             double t;
-                            if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                            if (ANY) {
+                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
+                            } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                                 best_t = t;
                                 best_ref = ref;
                             }
@@ -983,7 +855,7 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
             }
             cnt = 0u;
             bf = f32_above(best_t - tsh);
-            if (best_ref != REF_NONE && best_t - tsh <= (double)last_exit) running = false;
+            if (ANY ? best_ref != REF_NONE : (best_ref != REF_NONE && best_t - tsh <= (double)last_exit)) running = false;
         }
     }
 
@@ -992,7 +864,9 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
         for (int p = 0; p < sc.n_planes; ++p) {
             const DPlane &pl = sc.planes[p];
             double t;
-            if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+            if (ANY) {
+                if (best_ref == REF_NONE && plane_hit(pl, r, t_lo, t_hi, &t)) best_ref = REF_PLANE | p;
+            } else if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                 best_t = t;
                 best_ref = REF_PLANE | p;
             }
@@ -1005,10 +879,10 @@ DEV void traverse_closest_ww(const DScene &sc, const Ray &r, bool active, uint32
 
 template <int MODE>
 DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
-    // MODE_CLOSEST has its own entry point (traverse_closest_ww: wave-wide flushes, every lane must call it)
-    static_assert(MODE != MODE_CLOSEST, "use traverse_closest_ww");
-    if constexpr (MODE == MODE_ANY) traverse_any_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
-    else if constexpr (MODE == MODE_PRODUCT_FAST) traverse_product_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
+    // MODE_CLOSEST has its own entry point (traverse_ww: wave-wide flushes, every lane must call it)
+    static_assert(MODE != MODE_CLOSEST, "use traverse_ww");
+    static_assert(MODE != MODE_ANY, "use traverse_ww<true>");
+    if constexpr (MODE == MODE_PRODUCT_FAST) traverse_product_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
     else traverse_exact<MODE>(sc, r, s_lds + threadIdx.x, t_lo, t_hi, hit, prod);
 }
 
@@ -1265,7 +1139,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene
         const double *f = pool.f + slot;
         Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
                       : make_ray(v3(0, 0, 0), v3(0, 0, 1));
-        traverse_closest_ww(sc, r, valid, s_stk, s_cand, T_MIN, &hit);
+        traverse_ww<false>(sc, r, valid, s_stk, s_cand, T_MIN, inf(), &hit);
     } else if (valid) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
@@ -1497,6 +1371,7 @@ template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_ANY ? RTX_CAND_WORDS : 1];
     init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
@@ -1517,6 +1392,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
     }
 
     V3 v = v3(0, 0, 0);
+    Ray r = make_ray(v3(0, 0, 0), v3(0, 0, 1));
+    double distance_to_light = 0.0;
     if (valid) {
         const rtx_light &lt = sc.lights[light];
         V3 sampled = v3(lt.position[0], lt.position[1], lt.position[2]);
@@ -1527,8 +1404,16 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
             sampled = sampled + jitter;
         }
         V3 shadow_l = unit(sampled - hp);                                                // renderer.rs:203
-        Ray r = make_ray(hp, shadow_l);                                                  // NO origin offset (renderer.rs:204)
-        double distance_to_light = len(sampled - hp);
+        r = make_ray(hp, shadow_l);                                                      // NO origin offset (renderer.rs:204)
+        distance_to_light = len(sampled - hp);
+    }
+    if constexpr (MODE == MODE_ANY) {
+        // every lane of the wave takes part in the while-while walk (its flushes are wave-wide)
+        Hit hit;
+        traverse_ww<true>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit);
+        if (valid) v = hit.ref == REF_NONE ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+        WORK(count_work(valid, hit, counters->work[1]);)
+    } else if (valid) {
         Hit hit;
         traverse<MODE>(sc, r, s_stk, EPSILON, distance_to_light, &hit, &v);
         WORK(count_work(true, hit, counters->work[1]);)
@@ -1676,7 +1561,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         distance_to_light = len(sampled - hp);
     }
 
-    // ---- own ray in f32 (as traverse_any_fast) for the per-lane primitive box tests
+    // ---- own ray in f32 (as traverse_ww) for the per-lane primitive box tests
     const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
     const double tsh = re.t_shift;   // f32 frame re-based to where the ray enters the scene's cube
     const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
@@ -2077,7 +1962,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
     Ray r = make_ray(o, d);
     Hit hit;
     V3 unused;
-    if constexpr (MODE == MODE_CLOSEST) traverse_closest_ww(sc, r, true, s_stk, s_cand, T_MIN, &hit);
+    if constexpr (MODE == MODE_CLOSEST) traverse_ww<false>(sc, r, true, s_stk, s_cand, T_MIN, inf(), &hit);
     else traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     int pid = -1;
     if (hit.ref != REF_NONE) {

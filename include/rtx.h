@@ -179,10 +179,15 @@ typedef struct rtx_options {
 
 enum {
     RTX_FLAG_NO_COOP = 2,        /* shadow feelers walk the octree one ray per lane instead of the
-                                    cooperative 16-lane box-list traversal (A/B measurements) */
-    RTX_FLAG_REFERENCE_ORDER = 1 /* closest-hit ties resolve exactly as the reference's unordered
-                                    DFS would (first visited wins, ray.rs:52-60): disables
-                                    near-to-far culling. Slow; for parity experiments. */
+                                    cooperative 16-lane box-list traversal (A/B measurements; the
+                                    cooperative kernel is used for 4, 8 or a multiple of 16 tries per
+                                    hit point in scenes without transmissive materials) */
+    RTX_FLAG_REFERENCE_ORDER = 1 /* the all-f64 restatement of the reference's walks: closest-hit ties
+                                    resolve exactly as the reference's unordered DFS would (first
+                                    visited wins, ray.rs:52-60; no near-to-far culling), and in scenes
+                                    with transmissive materials the shadow product walks the octree
+                                    in f64 instead of classifying boxes in f32 first. Slow; for
+                                    parity experiments. */
 };
 
 typedef struct rtx_stats {

@@ -70,11 +70,20 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the trace path has no CPU fallback")
+    # Rehearsal switches for a one-GPU box (never set by the driver): RTX_BENCH_BACKEND=gloo runs the N > 1 flow with
+    # every rank on cuda:0 and the gather / reductions on host tensors, to exercise everything but RCCL itself.
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("rust-raytracer_amd")
     scene_name, W, H, fov, refl, refr, shadow, gloss, ps = WORKLOADS[args.workload]
@@ -92,7 +101,7 @@ def main():
 
     n_blocks = H // 8
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
-    gat = pkg.sharding.StillGather(W, H, rank, world, dev)
+    gat = pkg.sharding.StillGather(W, H, rank, world, comm_dev)
     final = gat.final
 
     opt = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
@@ -103,7 +112,7 @@ def main():
 
     def step():
         st = scene.render_device(cam, opt, rgba.data_ptr(), None, stream, want_stats=True)
-        gat.gather(rgba, dist)           # RCCL over xGMI: <= 1.04 MB per rank at 1080p (no-op copy at N=1)
+        gat.gather(rgba if comm_dev is dev else rgba.cpu(), dist)   # RCCL over xGMI: <= 1.04 MB per rank at 1080p (a copy at N=1)
         return st
 
     def barrier():
@@ -122,7 +131,7 @@ def main():
     rays = np.zeros(5, dtype=np.float64)
     for st in stats:
         rays += np.array([st.rays_primary, st.rays_reflect, st.rays_gloss, st.rays_refract, st.rays_shadow], dtype=np.float64)
-    agg = torch.tensor(list(rays) + [elapsed], dtype=torch.float64, device=dev)
+    agg = torch.tensor(list(rays) + [elapsed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         tmax = agg[5:].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

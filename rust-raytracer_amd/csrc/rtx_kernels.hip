@@ -244,7 +244,7 @@ DEV bool plane_hit(const DPlane &pl, const Ray &r, double t_min, double t_max, d
 //                    so exact-t ties between different prims resolve as in ray.rs:52-60.
 // MODE_ANY:          shadow feeler when every material is opaque: stop at the first occluder
 //                    inside [EPSILON, dist] (the product would be exactly 0 from there on).
-// MODE_PRODUCT_FAST: the same multiset as MODE_PRODUCT, boxes classified in f32 (traverse_product_fast).
+// MODE_PRODUCT_FAST: the same multiset as MODE_PRODUCT, boxes classified in f32 (traverse_ww<WW_PRODUCT>).
 // MODE_PRODUCT:      shadow feeler with transmissive materials: every candidate of the
 //                    multiset, duplicates included (renderer.rs:209-217), order-free product.
 enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4 };
@@ -424,7 +424,7 @@ DEV void traverse_exact(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, st
     else *prod = acc;
 }
 
-// Fast traversals (closest hit and per-lane any hit: traverse_ww, cooperative any hit: k_shadow_coop, shadow product: traverse_product_fast).  Node and leaf-entry boxes are tested in f32
+// Fast traversals (closest hit and per-lane any hit: traverse_ww, cooperative any hit: k_shadow_coop, shadow product: traverse_ww<WW_PRODUCT>).  Node and leaf-entry boxes are tested in f32
 // against the outward-rounded DNode32 / DEntry32 twins, widened by a per-ray delta that bounds
 // every rounding error of the f32 arithmetic (origin and inverse direction rounded to f32, one
 // subtraction and one multiplication per plane: < 2^-22 * S in position units, S = largest
@@ -489,169 +489,14 @@ DEV void init_lds(uint32_t *s_lds) {
 // by delta passed (cross-axis form, surely_hit) => the f64 test passes;  the few in between (a ray within delta
 // of a face or an edge, or an axis-parallel ray) are decided by the f64 test itself, with the child box computed
 // by the reference's own expressions (octree.rs:79-92).  Leaf entries go the same way (f32 reject, surely-in, or
-// the exact entry-bbox test), then the exact primitive test.  traverse_exact<MODE_PRODUCT> remains as the
-// all-f64 restatement (rtx_shadow_products, RTX_FLAG_REFERENCE_ORDER) the tests compare this walk with.
+// the exact entry-bbox test), then the exact primitive test.  The walk itself is traverse_ww<WW_PRODUCT> below;
+// traverse_exact<MODE_PRODUCT> remains as the all-f64 restatement (rtx_shadow_products,
+// RTX_FLAG_REFERENCE_ORDER) the tests compare this walk with.
 DEV bool surely_hit(float nx, float ny, float nz, float fx, float fy, float fz) {
     // n*: upper bounds of the near slab distances, f*: lower bounds of the far ones.  BBox::intersects passes iff every
     // cross-axis pair is ordered and the smallest far distance is > 0 (an axis is never compared with itself).
     return nx <= fminf(fy, fz) && ny <= fminf(fx, fz) && nz <= fminf(fx, fy) && fminf(fminf(fx, fy), fz) > 0.0f;
 }
-DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
-    uint32_t *stk = s_lds + threadIdx.x;   // level stack, stride RTX_BLOCK
-    const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
-    V3 acc = v3(1.0, 1.0, 1.0);            // shadow product (renderer.rs:211)
-    bool done = false;     // the walk is over
-    bool zero = false;     // the product has reached exactly (0,0,0): nothing can change it any more
-    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
-
-    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
-    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh; tsh >= 0, so "t > 0" holds whenever "t - tsh > 0"
-    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
-    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
-    const double delta = big * (1.0 / 1048576.0);
-    const bool sx = r.sx, sy = r.sy, sz = r.sz;
-    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
-    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
-    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
-    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
-    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
-    const uint32_t flip = r.flip;
-    const uint8_t *perm_row = perm + (flip << 8);
-    // the f32 frame starts where the ray enters the scene's cube: a box "in front of the origin" in the reference's
-    // sense may lie behind that point only if the origin is inside the cube, where tsh = 0
-    const float front = 0.0f;
-
-    int sp = 0;
-    uint32_t cur = 0;
-    bool have_cur = true;           // root: never tested (octree.rs:149,177)
-    if (re.miss) done = true;       // the ray misses the cube that holds every finite prim: no box inside it passes
-    while (!done) {
-        if (!have_cur) {
-            while (sp > 0 && (stk[(sp - 1) * RTX_BLOCK] & 0xFFu) == 0u) --sp;
-            if (sp == 0) break;
-            uint32_t e = stk[(sp - 1) * RTX_BLOCK];
-            uint32_t j = (uint32_t)__ffs((int)(e & 0xFFu)) - 1u;
-            stk[(sp - 1) * RTX_BLOCK] = e & ~(1u << j);
-            cur = (e >> 8) + (j ^ flip);
-        }
-        have_cur = false;
-        const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + cur);
-        const float4 qa = nq[0], qb = nq[1];
-        const float minx = qa.x, miny = qa.y, minz = qa.z, maxx = qa.w, maxy = qb.x, maxz = qb.y;
-        const uint32_t link = __float_as_uint(qb.z), aux = __float_as_uint(qb.w);
-        WORK(++w_nodes;)
-        if (aux == 0xFFFFFFFFu) {
-            const float pnx = sx ? minx : maxx, pfx = sx ? maxx : minx;
-            const float pny = sy ? miny : maxy, pfy = sy ? maxy : miny;
-            const float pnz = sz ? minz : maxz, pfz = sz ? maxz : minz;
-            const float mx = 0.5f * (minx + maxx), my = 0.5f * (miny + maxy), mz = 0.5f * (minz + maxz);
-            // per axis: near half = [p_near, mid], far half = [mid, p_far]; W = widened (cn on entries, cf on exits),
-            // S = shrunk (cf on entries, cn on exits)
-            const float wn0x = fmaf(pnx, ix, cnx), wn1x = fmaf(mx, ix, cnx), wf0x = fmaf(mx, ix, cfx), wf1x = fmaf(pfx, ix, cfx);
-            const float wn0y = fmaf(pny, iy, cny), wn1y = fmaf(my, iy, cny), wf0y = fmaf(my, iy, cfy), wf1y = fmaf(pfy, iy, cfy);
-            const float wn0z = fmaf(pnz, iz, cnz), wn1z = fmaf(mz, iz, cnz), wf0z = fmaf(mz, iz, cfz), wf1z = fmaf(pfz, iz, cfz);
-            const float sn0x = fmaf(pnx, ix, cfx), sn1x = fmaf(mx, ix, cfx), sf0x = fmaf(mx, ix, cnx), sf1x = fmaf(pfx, ix, cnx);
-            const float sn0y = fmaf(pny, iy, cfy), sn1y = fmaf(my, iy, cfy), sf0y = fmaf(my, iy, cny), sf1y = fmaf(pfy, iy, cny);
-            const float sn0z = fmaf(pnz, iz, cfz), sn1z = fmaf(mz, iz, cfz), sf0z = fmaf(mz, iz, cnz), sf1z = fmaf(pfz, iz, cnz);
-            uint32_t maybe = 0, sure = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) {
-                const float lo = fmaxf(fmaxf(fmaxf((j & 4u) ? wn1x : wn0x, front), (j & 2u) ? wn1y : wn0y), (j & 1u) ? wn1z : wn0z);
-                const float hi = fminf(fminf((j & 4u) ? wf1x : wf0x, (j & 2u) ? wf1y : wf0y), (j & 1u) ? wf1z : wf0z);
-                maybe |= (lo <= hi) ? (1u << j) : 0u;
-                const bool s_ = surely_hit((j & 4u) ? sn1x : sn0x, (j & 2u) ? sn1y : sn0y, (j & 1u) ? sn1z : sn0z,
-                                           (j & 4u) ? sf1x : sf0x, (j & 2u) ? sf1y : sf0y, (j & 1u) ? sf1z : sf0z);
-                sure |= s_ ? (1u << j) : 0u;
-            }
-            const uint32_t present = (uint32_t)perm_row[link & 0xFFu];   // children whose subtree holds an entry, in near-to-far bit order
-            if (!finite_dir) { maybe = 0xFFu; sure = 0u; }               // NaNs (0 * inf) in the f32 distances: let the f64 test decide
-            uint32_t pending = sure & present;
-            uint32_t border = maybe & ~sure & present;
-            if (border) {
-                // the reference's own child boxes and test (octree.rs:79-92, bbox.rs:99-165) for the undecided children
-                const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + cur);
-                const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
-                const double bminx = q0.x, bminy = q0.y, bminz = q1.x, bmaxx = q1.y, bmaxy = q2.x, bmaxz = q2.y;
-                const double hlx = (bmaxx - bminx) / 2.0, hly = (bmaxy - bminy) / 2.0, hlz = (bmaxz - bminz) / 2.0;
-                while (border) {
-                    const uint32_t j = (uint32_t)__ffs((int)border) - 1u;
-                    border &= border - 1u;
-                    const uint32_t k = j ^ flip;   // child index x*4 + y*2 + z
-                    const double cminx = (k & 4u) ? bminx + hlx : bminx, cmaxx = (k & 4u) ? bmaxx : bmaxx - hlx;
-                    const double cminy = (k & 2u) ? bminy + hly : bminy, cmaxy = (k & 2u) ? bmaxy : bmaxy - hly;
-                    const double cminz = (k & 1u) ? bminz + hlz : bminz, cmaxz = (k & 1u) ? bmaxz : bmaxz - hlz;
-                    double tn, tf;
-                    if (slab(cminx, cminy, cminz, cmaxx, cmaxy, cmaxz, r, &tn, &tf)) pending |= 1u << j;
-                }
-            }
-            if (pending) {
-                stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
-                ++sp;
-            }
-        } else {
-            const DEntry32 *ep = sc.entries32 + link;
-            for (uint32_t e = 0; e < aux && !zero; ++e) {
-                const float4 *eq = reinterpret_cast<const float4 *>(ep + e);
-                const float4 ea = eq[0], eb = eq[1];
-                WORK(++w_entries;)
-                const float enx = sx ? ea.x : ea.w, efx = sx ? ea.w : ea.x;
-                const float eny = sy ? ea.y : eb.x, efy = sy ? eb.x : ea.y;
-                const float enz = sz ? ea.z : eb.y, efz = sz ? eb.y : ea.z;
-                bool surely_in = false;
-                if (finite_dir) {
-                    // widened entry box missed => the exact entry-bbox test (octree.rs:170) fails
-                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), front), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
-                    const float hi = fminf(fminf(fmaf(efx, ix, cfx), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
-                    if (!(lo <= hi)) continue;
-                    surely_in = surely_hit(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy), fmaf(enz, iz, cfz), fmaf(efx, ix, cnx), fmaf(efy, iy, cny),
-                                           fmaf(efz, iz, cnz));
-                }
-                const int ref = __float_as_int(eb.z);
-                int mat;
-                bool occl = false;
-                if (ref >= 0) {
-                    int pid;
-                    TriV tr = load_tri(sc.tris, ref, &pid, &mat);
-                    if (!surely_in && !tri_bbox_hit(tr, r)) continue;
-                    WORK(++w_prims;)
-                    double t, be, ga;
-                    occl = tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga);
-                } else {
-                    const DSphere &sp_ = sc.spheres[~ref];
-                    V3 c = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
-                    mat = sp_.material;
-                    if (!surely_in && !sphere_bbox_hit(c, sp_.r, r)) continue;
-                    WORK(++w_prims;)
-                    double t;
-                    occl = sphere_hit(c, sp_.r, r, t_lo, t_hi, &t);
-                }
-                if (occl) {
-                    const rtx_material &m = sc.materials[mat];
-                    if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
-                    else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
-                    if (acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0) { zero = true; done = true; }   // finite factors: it stays exactly 0
-                }
-            }
-        }
-    }
-    // infinite prims last, in order (octree.rs:163-165,185-186)
-    if (!zero) {
-        for (int p = 0; p < sc.n_planes; ++p) {
-            const DPlane &pl = sc.planes[p];
-            double t;
-            if (plane_hit(pl, r, t_lo, t_hi, &t)) {
-                const rtx_material &m = sc.materials[pl.material];
-                if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
-                else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
-            }
-        }
-    }
-    hit->t = t_hi;
-    hit->ref = REF_NONE;
-    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
-    *prod = acc;
-}
-
 // Closest hit as a WHILE-WHILE walk with DEFERRED exact tests (k_closest, k_nearest).  Same nodes, same
 // conservative f32 tests and same exact f64 tests as the reference's walk, arranged so that the lanes of
 // a wave do the same kind of work at the same time:
@@ -680,8 +525,14 @@ DEV void traverse_product_fast(const DScene &sc, const Ray &r, uint32_t *s_lds, 
 #endif
 // ANY = true: the any-hit search of a shadow feeler (k_shadow<MODE_ANY>): the window is [t_lo, t_hi] for every candidate and
 // the lane stops at the first flush that finds an occluder.
-template <bool ANY>
-DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit) {
+// WW_PRODUCT: the shadow product over the reference's exact candidate multiset (classification of boxes: see surely_hit above): nothing is culled by distance, no mailbox, every hit multiplies `*prod`.
+enum { WW_CLOSEST = 0, WW_ANY = 1, WW_PRODUCT = 2 };
+template <int WW>
+DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
+                     V3 *prod = nullptr) {
+    constexpr bool ANY = WW == WW_ANY, PRODUCT = WW == WW_PRODUCT;
+    V3 acc = v3(1.0, 1.0, 1.0);   // WW_PRODUCT: renderer.rs:211
+    bool zero = false;            // ... has reached exactly (0,0,0)
     uint32_t *stk = s_lds + threadIdx.x;     // level stack, stride RTX_BLOCK
     uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
     const uint8_t *perm = reinterpret_cast<const uint8_t *>(s_lds + RTX_STK_WORDS);
@@ -702,7 +553,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     const uint32_t flip = r.flip;
     const uint8_t *perm_row = perm + (flip << 8);
-    float bf = f32_above(best_t - tsh);
+    float bf = PRODUCT ? __int_as_float(0x7F800000) : f32_above(best_t - tsh);   // the product culls nothing by distance
     int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
 
     int sp = 0;
@@ -757,6 +608,39 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                     pending |= (lo <= hi) ? (1u << j) : 0u;
                 }
                 pending &= (uint32_t)perm_row[link & 0xFFu];
+                if constexpr (PRODUCT) {
+                    // exactly the reference's node set: children the shrunk boxes surely pass are taken, the other
+                    // `pending` ones (within delta of the ray, or NaNs from an axis-parallel ray) are decided by the
+                    // reference's own f64 boxes and test (octree.rs:79-92, bbox.rs:99-165)
+                    const float s0x = fmaf(pnx, ix, cfx), s1x = fmaf(mx, ix, cfx), e0x = fmaf(mx, ix, cnx), e1x = fmaf(pfx, ix, cnx);
+                    const float s0y = fmaf(pny, iy, cfy), s1y = fmaf(my, iy, cfy), e0y = fmaf(my, iy, cny), e1y = fmaf(pfy, iy, cny);
+                    const float s0z = fmaf(pnz, iz, cfz), s1z = fmaf(mz, iz, cfz), e0z = fmaf(mz, iz, cnz), e1z = fmaf(pfz, iz, cnz);
+                    uint32_t sure = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        sure |= surely_hit((j & 4u) ? s1x : s0x, (j & 2u) ? s1y : s0y, (j & 1u) ? s1z : s0z, (j & 4u) ? e1x : e0x,
+                                           (j & 2u) ? e1y : e0y, (j & 1u) ? e1z : e0z) ? (1u << j) : 0u;
+                    uint32_t present = (uint32_t)perm_row[link & 0xFFu];
+                    if (!finite_dir) { pending = present; sure = 0u; }
+                    uint32_t border = pending & ~sure;
+                    pending &= sure;
+                    if (border) {
+                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + cur);
+                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                        const double bminx = q0.x, bminy = q0.y, bminz = q1.x, bmaxx = q1.y, bmaxy = q2.x, bmaxz = q2.y;
+                        const double hlx = (bmaxx - bminx) / 2.0, hly = (bmaxy - bminy) / 2.0, hlz = (bmaxz - bminz) / 2.0;
+                        while (border) {
+                            const uint32_t j = (uint32_t)__ffs((int)border) - 1u;
+                            border &= border - 1u;
+                            const uint32_t k = j ^ flip;   // child index x*4 + y*2 + z
+                            const double cminx = (k & 4u) ? bminx + hlx : bminx, cmaxx = (k & 4u) ? bmaxx : bmaxx - hlx;
+                            const double cminy = (k & 2u) ? bminy + hly : bminy, cmaxy = (k & 2u) ? bmaxy : bmaxy - hly;
+                            const double cminz = (k & 1u) ? bminz + hlz : bminz, cmaxz = (k & 1u) ? bmaxz : bmaxz - hlz;
+                            double tn, tf;
+                            if (slab(cminx, cminy, cminz, cmaxx, cmaxy, cmaxz, r, &tn, &tf)) pending |= 1u << j;
+                        }
+                    }
+                }
                 if (pending) {
                     stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
                     ++sp;
@@ -795,7 +679,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                     const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), bf), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
                     const int ref = __float_as_int(eb.z);
                     // mailbox: already parked or tested with a window at least as wide
-                    if (lo <= hi && ref != last_ref0 && ref != last_ref1) {
+                    if (lo <= hi && (PRODUCT || (ref != last_ref0 && ref != last_ref1))) {   // the product counts duplicates
                         last_ref1 = last_ref0;
                         last_ref0 = ref;
                         // the box shrunk by delta instead of widened: a ray through it passes the exact f64 entry
@@ -818,7 +702,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
         const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
         if (__any(stalled) || holders >= RTX_DEFER_FLUSH || !__any(running)) {
             for (uint32_t i = 0; __any(i < cnt); ++i) {
-                if (i < cnt && !(ANY && best_ref != REF_NONE)) {   // any-hit: one occluder is enough
+                if (i < cnt && !(ANY && best_ref != REF_NONE) && !zero) {   // any-hit: one occluder is enough
                     const uint32_t c = cand[i * RTX_BLOCK];
                     const int ref = (int)c >> 1;
                     const bool surely_in = (c & 1u) != 0u;
@@ -828,7 +712,14 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                         if (surely_in || tri_bbox_hit(tr, r)) {
                             WORK(++w_prims;)
                             double t, be, ga;
-                            if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
+                            if (PRODUCT) {
+                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
+                                    const rtx_material &m = sc.materials[mat];
+                                    if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                                    else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                                    zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
+                                }
+                            } else if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
                             } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
                                 // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
@@ -843,7 +734,14 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                         if (surely_in || sphere_bbox_hit(cc, radius, r)) {
                             WORK(++w_prims;)
                             double t;
-                            if (ANY) {
+                            if (PRODUCT) {
+                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) {
+                                    const rtx_material &m = sc.materials[sp_.material];
+                                    if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                                    else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                                    zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;
+                                }
+                            } else if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
                             } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                                 best_t = t;
@@ -854,8 +752,12 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                 }
             }
             cnt = 0u;
-            bf = f32_above(best_t - tsh);
-            if (ANY ? best_ref != REF_NONE : (best_ref != REF_NONE && best_t - tsh <= (double)last_exit)) running = false;
+            if constexpr (PRODUCT) {
+                if (zero) running = false;
+            } else {
+                bf = f32_above(best_t - tsh);
+                if (ANY ? best_ref != REF_NONE : (best_ref != REF_NONE && best_t - tsh <= (double)last_exit)) running = false;
+            }
         }
     }
 
@@ -864,7 +766,13 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
         for (int p = 0; p < sc.n_planes; ++p) {
             const DPlane &pl = sc.planes[p];
             double t;
-            if (ANY) {
+            if (PRODUCT) {
+                if (!zero && plane_hit(pl, r, t_lo, t_hi, &t)) {
+                    const rtx_material &m = sc.materials[pl.material];
+                    if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                    else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                }
+            } else if (ANY) {
                 if (best_ref == REF_NONE && plane_hit(pl, r, t_lo, t_hi, &t)) best_ref = REF_PLANE | p;
             } else if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                 best_t = t;
@@ -874,6 +782,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     }
     hit->t = best_t;
     hit->ref = best_ref;
+    if (PRODUCT) *prod = acc;
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 }
 
@@ -881,9 +790,8 @@ template <int MODE>
 DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
     // MODE_CLOSEST has its own entry point (traverse_ww: wave-wide flushes, every lane must call it)
     static_assert(MODE != MODE_CLOSEST, "use traverse_ww");
-    static_assert(MODE != MODE_ANY, "use traverse_ww<true>");
-    if constexpr (MODE == MODE_PRODUCT_FAST) traverse_product_fast(sc, r, s_lds, t_lo, t_hi, hit, prod);
-    else traverse_exact<MODE>(sc, r, s_lds + threadIdx.x, t_lo, t_hi, hit, prod);
+    static_assert(MODE != MODE_ANY && MODE != MODE_PRODUCT_FAST, "use traverse_ww<WW_ANY / WW_PRODUCT>");
+    traverse_exact<MODE>(sc, r, s_lds + threadIdx.x, t_lo, t_hi, hit, prod);
 }
 
 // ------------------------------------------------------------------------------ textures
@@ -1139,7 +1047,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene
         const double *f = pool.f + slot;
         Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
                       : make_ray(v3(0, 0, 0), v3(0, 0, 1));
-        traverse_ww<false>(sc, r, valid, s_stk, s_cand, T_MIN, inf(), &hit);
+        traverse_ww<WW_CLOSEST>(sc, r, valid, s_stk, s_cand, T_MIN, inf(), &hit);
     } else if (valid) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
@@ -1371,7 +1279,7 @@ template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[MODE == MODE_ANY ? RTX_CAND_WORDS : 1];
+    __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : 1];
     init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
@@ -1410,8 +1318,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
     if constexpr (MODE == MODE_ANY) {
         // every lane of the wave takes part in the while-while walk (its flushes are wave-wide)
         Hit hit;
-        traverse_ww<true>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit);
+        traverse_ww<WW_ANY>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit);
         if (valid) v = hit.ref == REF_NONE ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+        WORK(count_work(valid, hit, counters->work[1]);)
+    } else if constexpr (MODE == MODE_PRODUCT_FAST) {
+        Hit hit;
+        V3 pr = v3(0, 0, 0);
+        traverse_ww<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit, &pr);
+        if (valid) v = pr;
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if (valid) {
         Hit hit;
@@ -1962,7 +1876,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
     Ray r = make_ray(o, d);
     Hit hit;
     V3 unused;
-    if constexpr (MODE == MODE_CLOSEST) traverse_ww<false>(sc, r, true, s_stk, s_cand, T_MIN, inf(), &hit);
+    if constexpr (MODE == MODE_CLOSEST) traverse_ww<WW_CLOSEST>(sc, r, true, s_stk, s_cand, T_MIN, inf(), &hit);
     else traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     int pid = -1;
     if (hit.ref != REF_NONE) {

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--reflect", type=int, default=-1, help="override reflect_depth")
     ap.add_argument("--refract", type=int, default=-1, help="override refract_depth")
     ap.add_argument("--no-coop", action="store_true", help="RTX_FLAG_NO_COOP: per-lane octree shadows (A/B)")
+    ap.add_argument("--serial", action="store_true", help="RTX_FLAG_SERIAL: no overlap of shadow and closest-hit launches (A/B)")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,7 +108,7 @@ def main():
     opt = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
                       pixel_samples=ps, rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0,
                       shard_index=rank, shard_count=world, batch_rays=args.batch_rays,
-                      flags=pkg.abi.FLAG_NO_COOP if args.no_coop else 0)
+                      flags=(pkg.abi.FLAG_NO_COOP if args.no_coop else 0) | (pkg.abi.FLAG_SERIAL if args.serial else 0))
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -217,6 +218,11 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                                "avg_launch_ms": avg_ms, "launches_per_frame": launches,
+                               # > 1: launches run concurrently (the shadow launches of the two lights on the library's two
+                               # streams, next to the following step's closest-hit launch), so avg_launch_ms is a duration
+                               # under sharing; `bench.py --serial` times every kernel alone (profiles/*_serial*)
+                               "launch_concurrency": (ms_shadow + ms_closest) / max(1e-9, out["device_ms_rank0"]["frame"]),
+                               "overlap": not args.serial,
                                "algorithmic_bytes_per_ray": bpr, "rays_per_launch": nrays / max(1.0, launches),
                                # what the kernel physically does (profiles/): HBM rate = measured bytes per launch / live launch time;
                                # VALU figures from the SQ counter pass of the same command
@@ -226,7 +232,9 @@ def main():
                                        "counters: every pierced leaf, no early-out), which the GPU kernels avoid touching by ordered, "
                                        "culled, cooperative traversal, so frac > 1 is expected; traffic = measured HBM bytes per launch "
                                        "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes, profiles/); the kernel is "
-                                       "VALU-issue bound on cache-resident data (valu.busy), not HBM bound (hbm_measured_gbs vs peak)"}
+                                       "VALU-issue bound on cache-resident data (valu.busy), not HBM bound (hbm_measured_gbs vs peak); "
+                                       "with overlap (default) launches share the GPU, which lengthens avg_launch_ms and lowers achieved "
+                                       "while the frame gets shorter"}
         print(json.dumps(out), flush=True)
 
     scene.close()

@@ -172,12 +172,16 @@ typedef struct rtx_options {
      * shard_count == 0 means 1. */
     uint32_t shard_index;
     uint32_t shard_count;
-    uint32_t batch_rays;      /* rays traced per wavefront step (0 = default 4 Mi) */
+    uint32_t batch_rays;      /* rays traced per wavefront step (0 = default 8 Mi) */
     uint32_t pool_rays;       /* capacity of the ray pool in rays (0 = default: 8 x batch) */
     uint32_t flags;           /* RTX_FLAG_* */
 } rtx_options;
 
 enum {
+    RTX_FLAG_SERIAL = 4,         /* everything on the caller's stream, one launch after the other: by default the
+                                    shadow launches of a wavefront step run on a stream of the library's own and
+                                    overlap the next step's closest-hit launch (A/B measurements, clean per-kernel
+                                    timings; the image does not depend on it beyond the order of f64 atomic adds) */
     RTX_FLAG_NO_COOP = 2,        /* shadow feelers walk the octree one ray per lane instead of the
                                     cooperative 16-lane box-list traversal (A/B measurements; the
                                     cooperative kernel is used for 4, 8 or a multiple of 16 tries per

@@ -21,6 +21,7 @@ PRIM_SPHERE, PRIM_PLANE, PRIM_TRIANGLE = 0, 1, 2
 RNG_CENTER, RNG_PHILOX = 0, 1
 FLAG_REFERENCE_ORDER = 1
 FLAG_NO_COOP = 2
+FLAG_SERIAL = 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -177,7 +177,8 @@ typedef void *rtx_stream_t;
 
 void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count);
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
-                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref);
+                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
+                void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */);
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);

@@ -1913,7 +1913,8 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
     hipLaunchKernelGGL(k_generate, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, fr, pool, pool_base, s0, count);
 }
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
-                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref) {
+                DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
+                void *wait_before_shade, void *wait_before_shade2) {
     if (count == 0) return;
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
@@ -1921,6 +1922,8 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     else
         hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
                            counters, hit_t, hit_ref);
+    if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
+    if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
     hipLaunchKernelGGL(k_shade, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t, hit_ref,
                        sq, counters, acc, prim_id_out);
 }

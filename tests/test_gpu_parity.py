@@ -242,6 +242,30 @@ def test_cooperative_shadows_equal_per_lane_shadows(rtx, tries):
     assert sa.rays_total == sb.rays_total
 
 
+@pytest.mark.parametrize("which", ["mesh", "mesh_transmissive", "kitchen"])
+def test_overlapped_shadow_launches_equal_serial_launches(rtx, which):
+    """By default the shadow launches of a wavefront step run on the library's own stream and overlap the next
+    step's closest-hit launch (two alternating shadow queues); RTX_FLAG_SERIAL keeps every launch on the caller's
+    stream.  Same rays, same sums: the images may differ only by the order of the f64 atomic adds.  A small batch
+    makes many steps, so the queues alternate often."""
+    if which == "kitchen":
+        flat, cam_fn = scenes.kitchen_sink_scene(rtx)
+    else:
+        flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=(which == "mesh_transmissive"))
+    cam = cam_fn(160, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=4, refract_depth=4, shadow_samples=4, pixel_samples=2, rng_mode=1, seed=7, batch_rays=4096)
+    a, ia, sa = sc.render(cam, rtx.options(**kw))
+    b, ib, sb = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_SERIAL, **kw))
+    c, ic, sc_ = sc.render(cam, rtx.options(**kw))     # and again: the workspace (events, queues) is reused
+    sc.close()
+    assert sa.launches_closest > 8
+    assert np.array_equal(ia, ib) and np.array_equal(ia, ic)
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3
+    assert (np.abs(a.astype(int) - c.astype(int)) <= 1).all() and (a != c).mean() < 1e-3
+    assert sa.rays_total == sb.rays_total == sc_.rays_total
+
+
 @pytest.mark.parametrize("name,fov,opt", [
     ("bunny", 45.0, dict(reflect_depth=4, refract_depth=4, shadow_samples=1, pixel_samples=2)),
     ("sponza", 67.5, dict(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=1)),

@@ -1435,7 +1435,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     __shared__ uint2 s_pair[RTX_BLOCK / 64][RTX_COOP_PAIRS];
     __shared__ uint32_t s_hit[RTX_BLOCK];
     // every lane's feeler (origin, direction, inverse direction), read back by the lane that runs its exact tests
-    __shared__ double s_ray[6][RTX_BLOCK];      // direction, inverse direction per lane
+    __shared__ double s_ray[3][RTX_BLOCK];      // direction per lane (the inverse is recomputed where an exact entry-bbox test needs it)
+    // every lane's f32 traversal constants, read by whichever lanes test a queued primitive's box against this lane's ray:
+    // (ix, iy, iz, tmax_own | cnx, cny, cnz, - | cfx, cfy, cfz, -)
+    __shared__ float4 s_rayf[3][MULTI ? 1 : RTX_BLOCK];   // MULTI drains row by row, every lane its own ray
     __shared__ double s_org[3][MULTI ? RTX_BLOCK : RTX_BLOCK / 16];   // origin: per group (one hit point), or per lane
     // each group's beam (11 floats), re-read at every node step: they would otherwise sit in registers during the
     // exact tests, where the pressure peaks, and be spilled to scratch memory
@@ -1579,7 +1582,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // Group state, replicated in every lane of the group (it is computed from ballots only).
     // A LEVEL is a visited node with node-children still to visit: (tfirst, tmask) is the innermost
     // one, older ones are spilled to LDS.  Two nodes are tested per step (nodeA, nodeB).
+#ifdef RTX_ABL_NOWALK
+    uint32_t nodeA = NONE, nodeB = NONE;   // ablation: prologue and epilogue only
+#else
     uint32_t nodeA = a16 ? 0u : NONE, nodeB = NONE;
+#endif
     uint32_t tfirst = 0u, tmask = 0u, sp = 0u, qn = 0u;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
 
@@ -1631,14 +1638,24 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // read back from LDS).  Must be called by all 64 lanes.
     const uint32_t wid = threadIdx.x >> 6;
     uint32_t pair_n = 0u;           // wave-uniform
-    s_hit[threadIdx.x] = 0u;
+    s_hit[threadIdx.x] = (walk && !wide) ? 0u : 2u;   // bit 0: an occluder was found; bit 1: the lane's ray does not take part in the tests
     if (MULTI) { s_org[0][threadIdx.x] = r.ox; s_org[1][threadIdx.x] = r.oy; s_org[2][threadIdx.x] = r.oz; }
     else if (l16 == 0u) { s_org[0][sub] = r.ox; s_org[1][sub] = r.oy; s_org[2][sub] = r.oz; }
     s_ray[0][threadIdx.x] = r.dx; s_ray[1][threadIdx.x] = r.dy; s_ray[2][threadIdx.x] = r.dz;
-    s_ray[3][threadIdx.x] = r.ix; s_ray[4][threadIdx.x] = r.iy; s_ray[5][threadIdx.x] = r.iz;
+    if constexpr (!MULTI) {
+        s_rayf[0][threadIdx.x] = make_float4(ix, iy, iz, tmax_own);
+        s_rayf[1][threadIdx.x] = make_float4(cnx, cny, cnz, 0.0f);
+        s_rayf[2][threadIdx.x] = make_float4(cfx, cfy, cfz, 0.0f);
+    }
     COOP_FENCE();
+#ifdef RTX_COUNT_LOOPS
+    uint32_t c_steps = 0, c_drain = 0, c_pairs = 0, c_pairlanes = 0;
+#endif
     auto run_pairs = [&]() {
         const uint32_t n = pair_n < 64u ? pair_n : 64u;
+#ifdef RTX_COUNT_LOOPS
+        ++c_pairs; c_pairlanes += n;
+#endif
         pair_n -= n;
         const bool mine = lane < n;
         const uint2 pr = s_pair[wid][pair_n + (mine ? lane : 0u)];
@@ -1654,7 +1671,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             // tests' register peak down)
             auto entry_ray = [&]() {
                 Ray e = q;
-                e.ix = s_ray[3][owner]; e.iy = s_ray[4][owner]; e.iz = s_ray[5][owner];
+                e.ix = 1.0 / q.dx; e.iy = 1.0 / q.dy; e.iz = 1.0 / q.dz;   // as make_ray (ray.rs:29-33)
                 e.sx = e.ix > 0.0; e.sy = e.iy > 0.0; e.sz = e.iz > 0.0;
                 return e;
             };
@@ -1681,12 +1698,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             if (occluded) s_hit[owner] = 1u;
         }
         COOP_FENCE();
-        if (s_hit[threadIdx.x] != 0u) { alive = false; seek = false; }
+        if (s_hit[threadIdx.x] & 1u) { alive = false; seek = false; }
     };
 
     for (;;) {
         const bool g_on = nodeA != NONE;
         if (!__any(g_on)) break;
+#ifdef RTX_COUNT_LOOPS
+        ++c_steps;
+#endif
         if (g_on) {
             const bool hasB = nodeB != NONE;
             const float4 *pa = reinterpret_cast<const float4 *>(sc.wide + ((size_t)nodeA * RTX_WIDE + l16));
@@ -1739,44 +1759,110 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const bool walk_over = (tmask & 0xFFFFu) == 0u && sp == 0u;
         const bool want_x = g_on && (qn >= RTX_COOP_QT || (walk_over && qn > 0u));
         if (__any(want_x)) {
-            while (__any(qn > 0u)) {
-                bool push = false;
-                uint32_t pref = 0u, powner = lane;
-                if (qn > 0u) {
-                    --qn;
-                    COOP_FENCE();
-                    const uint32_t c = COOP_QUE(qn);
-                    if (seek) {
-                        const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
-                        const float4 c_lo = pc[0], c_hi = pc[1];
-                        const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
-                        WORK(++w_entries;)
-                        const float enx = sx ? lx : ux, efx = sx ? ux : lx;
-                        const float eny = sy ? ly : uy, efy = sy ? uy : ly;
-                        const float enz = sz ? lz : uz, efz = sz ? uz : lz;
-                        const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
-                        const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), tmax_own), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
-                        if (lo <= hi) {
-                            // the box shrunk by delta instead of widened: a ray through it passes the exact f64
-                            // entry test (octree.rs:170) with a margin far above f64 rounding
-                            bool surely_in = false;
-                            if (finite_dir) {
-                                const float li = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
-                                const float hi2 = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
-                                surely_in = li <= hi2 && hi2 > 0.0f;
+            if constexpr (!MULTI) {
+                // All four queues of the wave are drained together and the (primitive, group) items are dealt out evenly: every
+                // round, each 16-lane row takes ONE item and tests the primitive's box against the 16 rays of the item's group
+                // (their f32 constants come from LDS).  Row-bound draining (each row its own queue) ran max(queue length)
+                // rounds: measured 14.2 rounds per wave for 6.0 box tests per ray.
+                const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)qn, 0), q1 = (uint32_t)__builtin_amdgcn_readlane((int)qn, 16);
+                const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)qn, 32), q3 = (uint32_t)__builtin_amdgcn_readlane((int)qn, 48);
+#ifdef RTX_ABL_NODRAIN
+                const uint32_t p1 = q0, p2 = q0 + q1, p3 = p2 + q2, total = 0u * (p3 + q3);   // ablation: the walk alone
+#else
+                const uint32_t p1 = q0, p2 = q0 + q1, p3 = p2 + q2, total = p3 + q3;
+#endif
+                COOP_FENCE();
+                for (uint32_t base = 0u; base < total; base += 4u) {
+#ifdef RTX_COUNT_LOOPS
+                    ++c_drain;
+#endif
+                    const uint32_t item = base + (lane >> 4);
+                    bool push = false;
+                    uint32_t pref = 0u, powner = lane;
+                    if (item < total) {
+                        const uint32_t g = item < p1 ? 0u : (item < p2 ? 1u : (item < p3 ? 2u : 3u));
+                        const uint32_t qi = item - (g == 0u ? 0u : (g == 1u ? p1 : (g == 2u ? p2 : p3)));
+                        const uint32_t c = s_queue[(wid << 2) + g][qi];
+                        const uint32_t ol = (g << 4) | l16;               // the ray's lane in the wave
+                        const uint32_t ot = (threadIdx.x & ~63u) + ol;    // ... and in the workgroup
+                        if (s_hit[ot] == 0u) {
+                            const float4 ra = s_rayf[0][ot], rn = s_rayf[1][ot], rf = s_rayf[2][ot];
+                            const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
+                            const float4 c_lo = pc[0], c_hi = pc[1];
+                            const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
+                            WORK(++w_entries;)
+                            const bool osx = ra.x > 0.0f, osy = ra.y > 0.0f, osz = ra.z > 0.0f;   // = Ray.signs: |1/d| >= 1 survives the rounding to f32
+                            const float enx = osx ? lx : ux, efx = osx ? ux : lx;
+                            const float eny = osy ? ly : uy, efy = osy ? uy : ly;
+                            const float enz = osz ? lz : uz, efz = osz ? uz : lz;
+                            const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ra.x, rn.x), 0.0f), fmaf(eny, ra.y, rn.y)), fmaf(enz, ra.z, rn.z));
+                            const float hi = fminf(fminf(fminf(fmaf(efx, ra.x, rf.x), ra.w), fmaf(efy, ra.y, rf.y)), fmaf(efz, ra.z, rf.z));
+                            if (lo <= hi) {
+                                // the box shrunk by delta instead of widened: a ray through it passes the exact f64
+                                // entry test (octree.rs:170) with a margin far above f64 rounding
+                                bool surely_in = false;
+                                if (fabsf(ra.x) < 3.0e38f && fabsf(ra.y) < 3.0e38f && fabsf(ra.z) < 3.0e38f) {
+                                    const float li = fmaxf(fmaxf(fmaf(enx, ra.x, rf.x), fmaf(eny, ra.y, rf.y)), fmaf(enz, ra.z, rf.z));
+                                    const float hi2 = fminf(fminf(fmaf(efx, ra.x, rn.x), fmaf(efy, ra.y, rn.y)), fmaf(efz, ra.z, rn.z));
+                                    surely_in = li <= hi2 && hi2 > 0.0f;
+                                }
+                                push = true;
+                                pref = __float_as_uint(c_hi.z);
+                                powner = ol | (surely_in ? 64u : 0u);
                             }
-                            push = true;
-                            pref = __float_as_uint(c_hi.z);
-                            powner = lane | (surely_in ? 64u : 0u);
                         }
                     }
+                    const unsigned long long pm = __ballot(push);
+                    if (pm != 0ull) {
+                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(pref, powner);
+                        pair_n += (uint32_t)__popcll(pm);
+                        COOP_FENCE();
+                        if (pair_n >= 64u) run_pairs();
+                    }
                 }
-                const unsigned long long pm = __ballot(push);
-                if (pm != 0ull) {
-                    if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(pref, powner);
-                    pair_n += (uint32_t)__popcll(pm);
-                    COOP_FENCE();
-                    if (pair_n >= 64u) run_pairs();
+                qn = 0u;
+            } else {
+                // groups of several hit points: every row drains its own queue, each lane against its own ray (constants in
+                // registers; the per-lane copies in LDS would cost this variant its fifth workgroup per CU)
+                while (__any(qn > 0u)) {
+                    bool push = false;
+                    uint32_t pref = 0u, powner = lane;
+                    if (qn > 0u) {
+                        --qn;
+                        COOP_FENCE();
+                        const uint32_t c = COOP_QUE(qn);
+                        if (seek) {
+                            const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
+                            const float4 c_lo = pc[0], c_hi = pc[1];
+                            const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
+                            WORK(++w_entries;)
+                            const float enx = sx ? lx : ux, efx = sx ? ux : lx;
+                            const float eny = sy ? ly : uy, efy = sy ? uy : ly;
+                            const float enz = sz ? lz : uz, efz = sz ? uz : lz;
+                            const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
+                            const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), tmax_own), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
+                            if (lo <= hi) {
+                                // the box shrunk by delta instead of widened: a ray through it passes the exact f64
+                                // entry test (octree.rs:170) with a margin far above f64 rounding
+                                bool surely_in = false;
+                                if (finite_dir) {
+                                    const float li = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
+                                    const float hi2 = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
+                                    surely_in = li <= hi2 && hi2 > 0.0f;
+                                }
+                                push = true;
+                                pref = __float_as_uint(c_hi.z);
+                                powner = lane | (surely_in ? 64u : 0u);
+                            }
+                        }
+                    }
+                    const unsigned long long pm = __ballot(push);
+                    if (pm != 0ull) {
+                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(pref, powner);
+                        pair_n += (uint32_t)__popcll(pm);
+                        COOP_FENCE();
+                        if (pair_n >= 64u) run_pairs();
+                    }
                 }
             }
             if (pair_n >= RTX_COOP_PT) run_pairs();
@@ -1804,7 +1890,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
             if (plane_hit(sc.planes[p], q, EPSILON, distance_to_light, &t)) { alive = false; break; }
         }
     }
-#ifdef RTX_COUNT_WORK
+#ifdef RTX_COUNT_LOOPS
+    if (lane == 0u) {   // per wave: loop steps, drain rounds, run_pairs calls (high 32 bits of [2]: lanes busy in them)
+        atomicAdd(&counters->work[1][0], (unsigned long long)c_steps);
+        atomicAdd(&counters->work[1][1], (unsigned long long)c_drain);
+        atomicAdd(&counters->work[1][2], (unsigned long long)c_pairs + ((unsigned long long)c_pairlanes << 24));
+    }
+#elif defined(RTX_COUNT_WORK)
     if (valid) {
         atomicAdd(&counters->work[1][0], (unsigned long long)w_nodes);
         atomicAdd(&counters->work[1][1], (unsigned long long)w_entries);

@@ -445,6 +445,14 @@ struct RootEntry {
 };
 DEV RootEntry root_entry(const DScene &sc, const Ray &r, double orx, double ory, double orz) {
     const double R = sc.radius * 1.000001;
+    RootEntry e;
+    // an origin inside the cube (every reflection ray and shadow feeler that starts on a finite prim): each axis has one plane
+    // behind the origin, so tin stays 0 and the ray cannot miss; the slab distances are computed only if some lane is outside
+    if (fabs(orx) <= R && fabs(ory) <= R && fabs(orz) <= R) {
+        e.miss = false;
+        e.t_shift = 0.0;
+        return e;
+    }
     double tin = 0.0, tout = inf();
     bool miss = false;
     const double oo[3] = {orx, ory, orz}, dd[3] = {r.dx, r.dy, r.dz}, ii[3] = {r.ix, r.iy, r.iz};
@@ -458,7 +466,6 @@ DEV RootEntry root_entry(const DScene &sc, const Ray &r, double orx, double ory,
             miss = true;
         }
     }
-    RootEntry e;
     e.miss = miss || tin > tout;
     e.t_shift = tin;     // >= 0
     return e;
@@ -1333,7 +1340,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
         WORK(count_work(true, hit, counters->work[1]);)
     }
     double inv_tries = 1.0 / (double)tries;
-    if (pow2_tries) {
+    if (MODE == MODE_ANY && pow2_tries) {
+        // any-hit answers are 0 or 1: the group's sum is a population count (exact, like the butterfly below)
+        const uint32_t ln = threadIdx.x & 63u;
+        const unsigned long long clear = __ballot(valid && v.x != 0.0);
+        const unsigned long long mine = tries >= 64u ? ~0ull : (((1ull << tries) - 1ull) << (ln & ~(tries - 1u)));
+        const double n_clear = (double)__popcll(clear & mine);
+        if (valid && k == 0u) acc_add(acc, sample, w * scale(v3(n_clear, n_clear, n_clear), inv_tries));             // renderer.rs:220,118
+    } else if (pow2_tries) {
         // groups are lane-aligned (tries divides 64 and RTX_BLOCK): butterfly sum over the group
         for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
             v.x += __shfl_xor(v.x, (int)off);
@@ -1543,7 +1557,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         const float spread = fmaxf(fmaxf(o0max - o0min, o1max - o1min), o2max - o2min);   // NaN / -inf (no walker): not wide
         wide = !beam_ok || spread > RTX_COOP_WIDE * (float)sc.radius;
     }
-    const double inv0 = 1.0 / fabs(d0);
+    // 1 / |d0| = |1 / d0|: the ray's own inverse direction (make_ray), no second division
+    const double inv0 = fabs(a0 == 0 ? r.ix : (a0 == 1 ? r.iy : r.iz));
     grp_min_max(walk ? f32_below(d1 * inv0) : INF, walk ? f32_above(d1 * inv0) : -INF, &m1L, &m1H);
     grp_min_max(walk ? f32_below(d2 * inv0) : INF, walk ? f32_above(d2 * inv0) : -INF, &m2L, &m2H);
     const float umax = grp_max(walk ? f32_above((distance_to_light - tsh) * fabs(d0)) : 0.0f);
@@ -1566,6 +1581,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         m1L = m1H = m2L = m2H = 0.0f;
         umax_w = 1.0f;
     }
+    const bool pos1L = m1L >= 0.0f, pos1H = m1H >= 0.0f, pos2L = m2L >= 0.0f, pos2H = m2H >= 0.0f;
     if (l16 == 0u) {
         float *bm = s_beam[sub];
         bm[0] = o0min; bm[1] = o0max; bm[2] = o1min; bm[3] = o1max; bm[4] = o2min; bm[5] = o2max;
@@ -1600,8 +1616,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
         float u1 = neg0 ? (o0max - c0l) : (c0h - o0min);      // largest
         u0 = fmaxf(u0, 0.0f);
         u1 = fminf(u1, umax_w);
-        const float b1lo = o1min + fminf(u0 * m1L, u1 * m1L), b1hi = o1max + fmaxf(u0 * m1H, u1 * m1H);
-        const float b2lo = o2min + fminf(u0 * m2L, u1 * m2L), b2hi = o2max + fmaxf(u0 * m2H, u1 * m2H);
+        // min(u0 * m, u1 * m) over u0 <= u1 is taken at u0 for m >= 0 and at u1 otherwise (max: the other way round); the signs of
+        // the four slopes are group constants (pos1L ..), so each bound is one select and one FMA (rounded once: closer to the exact
+        // bound than the product and sum the slack was sized for)
+        const float b1lo = fmaf(pos1L ? u0 : u1, m1L, o1min), b1hi = fmaf(pos1H ? u1 : u0, m1H, o1max);
+        const float b2lo = fmaf(pos2L ? u0 : u1, m2L, o2min), b2hi = fmaf(pos2H ? u1 : u0, m2H, o2max);
         return u0 <= u1 && b1lo <= c1h && b1hi >= c1l && b2lo <= c2h && b2hi >= c2l;
     };
     // record = (lo.x, lo.y, lo.z, hi.x | hi.y, hi.z, ref, first_node); AX = dominant axis known at compile time,
@@ -1908,11 +1927,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     // the group's weight (light colour x material sample x path throughput) is fetched only now, by the lanes
     // that add to the accumulator: held in registers across the walk it would be spilled to scratch memory
     if (pow2_tries) {
-        for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
-            v.x += __shfl_xor(v.x, (int)off);
-            v.y += __shfl_xor(v.y, (int)off);
-            v.z += __shfl_xor(v.z, (int)off);
-        }
+        // the sum of the group's 0 / 1 answers is the number of its clear feelers: a ballot and a population count give the same
+        // (exact) f64 value as the butterfly of additions
+        const unsigned long long clear = __ballot(valid && alive);
+        const unsigned long long mine = tries >= 64u ? ~0ull : (((1ull << tries) - 1ull) << (lane & ~(tries - 1u)));
+        const double n_clear = (double)__popcll(clear & mine);
+        v = v3(n_clear, n_clear, n_clear);
     }
     uint32_t t2 = threadIdx.x;
     asm volatile("" : "+v"(t2));   // group / try index and loads afresh, not the prologue's values kept alive

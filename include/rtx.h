@@ -255,7 +255,10 @@ rtx_status rtx_render(rtx_scene *scene, const rtx_camera *camera, const rtx_opti
  * `stream` (a hipStream_t passed as void*, NULL = default stream).  The call returns after the
  * last kernel has been enqueued and the pool bookkeeping it needs has completed; the caller
  * synchronises the stream before reading the outputs.  This is the entry point bench.py and
- * the multi-GPU gather use: nothing crosses PCIe inside it. */
+ * the multi-GPU gather use: nothing crosses PCIe inside it.  Unless RTX_FLAG_SERIAL is set the
+ * shadow launches run on two non-blocking streams that belong to the scene handle; they are ordered
+ * against `stream` with events in both directions (they start after the step's shading on `stream`,
+ * and `stream` waits for them before the resolve), so the caller sees ordinary stream semantics. */
 rtx_status rtx_render_device(rtx_scene *scene, const rtx_camera *camera, const rtx_options *options,
                              void *rgba_out_dev, void *primary_prim_id_out_dev, void *stream,
                              rtx_stats *stats);

@@ -223,6 +223,24 @@ def test_bad_arguments(rtx):
     sc.close()
 
 
+def test_pool_exhaustion_is_an_error_and_leaves_the_handle_usable(rtx):
+    """A ray pool too small for the recursion fails with RTX_ERR_QUEUE_OVERFLOW (no path is dropped silently), with the
+    shadow launches that were already running on the library's streams drained; the same handle then renders the
+    frame correctly with the default pool."""
+    flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=True)
+    cam = cam_fn(160, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=8, refract_depth=8, shadow_samples=2, pixel_samples=2, rng_mode=1, seed=3)
+    good, ids, st = sc.render(cam, rtx.options(**kw))
+    with pytest.raises(rtx.abi.RtxError) as err:
+        sc.render(cam, rtx.options(batch_rays=16384, pool_rays=16384, **kw))
+    assert err.value.status == rtx.abi.RTX_ERR_QUEUE_OVERFLOW
+    again, ids2, st2 = sc.render(cam, rtx.options(**kw))
+    sc.close()
+    assert np.array_equal(ids, ids2) and st.rays_total == st2.rays_total
+    assert (np.abs(good.astype(int) - again.astype(int)) <= 1).all() and (good != again).mean() < 1e-3
+
+
 @pytest.mark.parametrize("tries", [1, 2, 4, 8, 16, 32, 3])
 def test_cooperative_shadows_equal_per_lane_shadows(rtx, tries):
     """The cooperative 16-lane box-list traversal and the per-lane octree walk are two exact any-hit

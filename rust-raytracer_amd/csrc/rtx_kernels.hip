@@ -523,7 +523,16 @@ DEV bool surely_hit(float nx, float ny, float nz, float fx, float fy, float fz) 
 #ifndef RTX_DEFER_FLUSH
 #define RTX_DEFER_FLUSH 24    // flush once this many lanes hold parked candidates
 #endif
-#define RTX_CAND_WORDS (RTX_DEFER_CAP * RTX_BLOCK)
+// Per-lane MAILBOX behind the parked candidates: a direct-mapped set of RTX_MAILBOX prim refs (slot = ref mod RTX_MAILBOX).  The entry-bbox
+// test and the prim test do not depend on the leaf that lists the prim, and the reference's octree lists a prim in every leaf its box
+// overlaps (heptoroid stand-in: 12.5 leaves per triangle, 47 exact tests per shadow feeler of which most repeat an earlier one), so:
+//   closest / any hit: a prim enters the set when it is parked; a later copy would be tested with a window at most as wide and is skipped;
+//   shadow product:    a prim enters the set when its exact tests have FAILED: its copies contribute nothing either.  Prims that were hit
+//                      are tested again in every leaf (the product counts each copy, renderer.rs:209-217).
+#ifndef RTX_MAILBOX
+#define RTX_MAILBOX 8
+#endif
+#define RTX_CAND_WORDS ((RTX_DEFER_CAP + RTX_MAILBOX) * RTX_BLOCK)
 #ifndef RTX_DESCENT_STEPS
 #define RTX_DESCENT_STEPS 4   // nodes a lane may visit per round before the wave moves on to the entry scans
 #endif
@@ -561,7 +570,9 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     const uint32_t flip = r.flip;
     const uint8_t *perm_row = perm + (flip << 8);
     float bf = PRODUCT ? __int_as_float(0x7F800000) : f32_above(best_t - tsh);   // the product culls nothing by distance
-    int last_ref0 = REF_NONE, last_ref1 = REF_NONE;   // tiny mailbox: a prim spanning adjacent leaves
+    uint32_t *mbx = s_cand + RTX_DEFER_CAP * RTX_BLOCK + threadIdx.x;   // mailbox slots, stride RTX_BLOCK
+#pragma unroll
+    for (uint32_t k = 0; k < RTX_MAILBOX; ++k) mbx[k * RTX_BLOCK] = (uint32_t)REF_NONE;
 
     int sp = 0;
     bool at_root = true;                       // root: never culled (octree.rs:149,177)
@@ -686,9 +697,9 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                     const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), bf), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
                     const int ref = __float_as_int(eb.z);
                     // mailbox: already parked or tested with a window at least as wide
-                    if (lo <= hi && (PRODUCT || (ref != last_ref0 && ref != last_ref1))) {   // the product counts duplicates
-                        last_ref1 = last_ref0;
-                        last_ref0 = ref;
+                    uint32_t *mslot = mbx + ((uint32_t)ref & (RTX_MAILBOX - 1u)) * RTX_BLOCK;
+                    if (lo <= hi && *mslot != (uint32_t)ref) {
+                        if (!PRODUCT) *mslot = (uint32_t)ref;
                         // the box shrunk by delta instead of widened: a ray through it passes the exact f64 entry
                         // test with a margin far above f64 rounding, so that test can be skipped
                         bool surely_in = false;
@@ -716,6 +727,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                     if (ref >= 0) {
                         int pid, mat;
                         TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                        bool occl = false;   // product: both the entry-bbox test and the prim test passed
                         if (surely_in || tri_bbox_hit(tr, r)) {
                             WORK(++w_prims;)
                             double t, be, ga;
@@ -725,6 +737,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                                     if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
                                     else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
                                     zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
+                                    occl = true;
                                 }
                             } else if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
@@ -734,10 +747,12 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                                 best_ref = ref;
                             }
                         }
+                        if (PRODUCT && !occl) mbx[((uint32_t)ref & (RTX_MAILBOX - 1u)) * RTX_BLOCK] = (uint32_t)ref;   // its copies miss too
                     } else {
                         const DSphere &sp_ = sc.spheres[~ref];
                         V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
                         double radius = sp_.r;
+                        bool occl = false;
                         if (surely_in || sphere_bbox_hit(cc, radius, r)) {
                             WORK(++w_prims;)
                             double t;
@@ -747,6 +762,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                                     if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
                                     else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
                                     zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;
+                                    occl = true;
                                 }
                             } else if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
@@ -755,6 +771,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                                 best_ref = ref;
                             }
                         }
+                        if (PRODUCT && !occl) mbx[((uint32_t)ref & (RTX_MAILBOX - 1u)) * RTX_BLOCK] = (uint32_t)ref;
                     }
                 }
             }

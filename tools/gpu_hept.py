@@ -9,7 +9,8 @@ named = pkg.host.NamedScene("heptoroid-refractive")
 cam = named.camera(W, H, 45.0)
 sc = pkg.Scene(named)
 for depth in [int(a) for a in sys.argv[3:]]:
-    opt = pkg.options(reflect_depth=depth, refract_depth=depth, shadow_samples=1, pixel_samples=1, rng_mode=1, seed=0)
+    opt = pkg.options(reflect_depth=depth, refract_depth=depth, shadow_samples=1, pixel_samples=1, rng_mode=1, seed=0,
+                      batch_rays=int(os.environ.get("RTX_BATCH", "0")), flags=int(os.environ.get("RTX_FLAGS", "0")))
     t0 = time.time()
     rgba, ids, st = sc.render(cam, opt, want_ids=False)
     dt = time.time() - t0

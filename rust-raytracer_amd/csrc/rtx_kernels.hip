@@ -490,15 +490,15 @@ DEV void init_lds(uint32_t *s_lds) {
 }
 // Shadow PRODUCT over the reference's exact candidate multiset (scenes with transmissive materials,
 // renderer.rs:209-217), at f32 speed.  The product needs every primitive once per leaf that the reference's
-// walk reaches and that lists it, so the walk must visit EXACTLY the nodes whose boxes pass BBox::intersects in
-// f64 (bbox.rs:99-165: no ray range, only "in front of the origin") — no culling by distance, no mailbox.
-// Each child box is classified in f32:  the box widened by delta missed => the f64 test fails;  the box shrunk
-// by delta passed (cross-axis form, surely_hit) => the f64 test passes;  the few in between (a ray within delta
-// of a face or an edge, or an axis-parallel ray) are decided by the f64 test itself, with the child box computed
-// by the reference's own expressions (octree.rs:79-92).  Leaf entries go the same way (f32 reject, surely-in, or
-// the exact entry-bbox test), then the exact primitive test.  The walk itself is traverse_ww<WW_PRODUCT> below;
-// traverse_exact<MODE_PRODUCT> remains as the all-f64 restatement (rtx_shadow_products,
-// RTX_FLAG_REFERENCE_ORDER) the tests compare this walk with.
+// walk reaches and that lists it (no culling by distance; BBox::intersects, bbox.rs:99-165, has no ray range, only
+// "in front of the origin").  Boxes are classified in f32:  the box widened by delta missed => the f64 test fails;
+// the box shrunk by delta passed (cross-axis form, surely_hit) => the f64 test passes;  the few in between (a ray
+// within delta of a face or an edge) are decided by the f64 test itself on the stored f64 box.  Because child boxes
+// are nested exactly and the test is monotone in the box (see traverse_ww, leaf branch), only LEAF boxes need the
+// exact decision; interior nodes are descended on the widened test.  Leaf entries go the same way (f32 reject,
+// surely-in, or the exact entry-bbox test), then the exact primitive test.  The walk itself is
+// traverse_ww<WW_PRODUCT> below; traverse_exact<MODE_PRODUCT> remains as the all-f64 restatement
+// (rtx_shadow_products, RTX_FLAG_REFERENCE_ORDER, axis-parallel feelers) the tests compare this walk with.
 DEV bool surely_hit(float nx, float ny, float nz, float fx, float fy, float fz) {
     // n*: upper bounds of the near slab distances, f*: lower bounds of the far ones.  BBox::intersects passes iff every
     // cross-axis pair is ordered and the smallest far distance is > 0 (an axis is never compared with itself).
@@ -541,11 +541,12 @@ DEV bool surely_hit(float nx, float ny, float nz, float fx, float fy, float fz) 
 #endif
 // ANY = true: the any-hit search of a shadow feeler (k_shadow<MODE_ANY>): the window is [t_lo, t_hi] for every candidate and
 // the lane stops at the first flush that finds an occluder.
-// WW_PRODUCT: the shadow product over the reference's exact candidate multiset (classification of boxes: see surely_hit above): nothing is culled by distance, no mailbox, every hit multiplies `*prod`.
+// WW_PRODUCT: the shadow product over the reference's exact candidate multiset (classification of boxes: see surely_hit above): nothing is
+// culled by distance, the mailbox holds known misses only, every hit multiplies `*prod`; *fallback = the caller must run the all-f64 walk.
 enum { WW_CLOSEST = 0, WW_ANY = 1, WW_PRODUCT = 2 };
 template <int WW>
 DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
-                     V3 *prod = nullptr) {
+                     V3 *prod = nullptr, bool *fallback = nullptr) {
     constexpr bool ANY = WW == WW_ANY, PRODUCT = WW == WW_PRODUCT;
     V3 acc = v3(1.0, 1.0, 1.0);   // WW_PRODUCT: renderer.rs:211
     bool zero = false;            // ... has reached exactly (0,0,0)
@@ -577,6 +578,9 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     int sp = 0;
     bool at_root = true;                       // root: never culled (octree.rs:149,177)
     bool running = active && !re.miss;         // a ray that misses the scene's cube has no finite candidate
+    // WW_PRODUCT: a ray with an infinite inverse direction component (0 * inf = NaN slab distances) goes to the caller's all-f64 walk
+    const bool fb = PRODUCT && active && !finite_dir;
+    if (fb) running = false;
     uint32_t cnt = 0;                          // parked candidates
     uint32_t e_cur = 0, e_end = 0;             // position in the current leaf's entry list (absolute indices)
     const float NEG_INF = __int_as_float(0xFF800000);
@@ -626,39 +630,6 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                     pending |= (lo <= hi) ? (1u << j) : 0u;
                 }
                 pending &= (uint32_t)perm_row[link & 0xFFu];
-                if constexpr (PRODUCT) {
-                    // exactly the reference's node set: children the shrunk boxes surely pass are taken, the other
-                    // `pending` ones (within delta of the ray, or NaNs from an axis-parallel ray) are decided by the
-                    // reference's own f64 boxes and test (octree.rs:79-92, bbox.rs:99-165)
-                    const float s0x = fmaf(pnx, ix, cfx), s1x = fmaf(mx, ix, cfx), e0x = fmaf(mx, ix, cnx), e1x = fmaf(pfx, ix, cnx);
-                    const float s0y = fmaf(pny, iy, cfy), s1y = fmaf(my, iy, cfy), e0y = fmaf(my, iy, cny), e1y = fmaf(pfy, iy, cny);
-                    const float s0z = fmaf(pnz, iz, cfz), s1z = fmaf(mz, iz, cfz), e0z = fmaf(mz, iz, cnz), e1z = fmaf(pfz, iz, cnz);
-                    uint32_t sure = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j)
-                        sure |= surely_hit((j & 4u) ? s1x : s0x, (j & 2u) ? s1y : s0y, (j & 1u) ? s1z : s0z, (j & 4u) ? e1x : e0x,
-                                           (j & 2u) ? e1y : e0y, (j & 1u) ? e1z : e0z) ? (1u << j) : 0u;
-                    uint32_t present = (uint32_t)perm_row[link & 0xFFu];
-                    if (!finite_dir) { pending = present; sure = 0u; }
-                    uint32_t border = pending & ~sure;
-                    pending &= sure;
-                    if (border) {
-                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + cur);
-                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
-                        const double bminx = q0.x, bminy = q0.y, bminz = q1.x, bmaxx = q1.y, bmaxy = q2.x, bmaxz = q2.y;
-                        const double hlx = (bmaxx - bminx) / 2.0, hly = (bmaxy - bminy) / 2.0, hlz = (bmaxz - bminz) / 2.0;
-                        while (border) {
-                            const uint32_t j = (uint32_t)__ffs((int)border) - 1u;
-                            border &= border - 1u;
-                            const uint32_t k = j ^ flip;   // child index x*4 + y*2 + z
-                            const double cminx = (k & 4u) ? bminx + hlx : bminx, cmaxx = (k & 4u) ? bmaxx : bmaxx - hlx;
-                            const double cminy = (k & 2u) ? bminy + hly : bminy, cmaxy = (k & 2u) ? bmaxy : bmaxy - hly;
-                            const double cminz = (k & 1u) ? bminz + hlz : bminz, cmaxz = (k & 1u) ? bmaxz : bmaxz - hlz;
-                            double tn, tf;
-                            if (slab(cminx, cminy, cminz, cmaxx, cmaxy, cmaxz, r, &tn, &tf)) pending |= 1u << j;
-                        }
-                    }
-                }
                 if (pending) {
                     stk[sp * RTX_BLOCK] = (link & 0xFFFFFF00u) | pending;
                     ++sp;
@@ -666,9 +637,27 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
             } else {
                 // exit taken with delta the OTHER way (cn on a far plane): a lower bound of the true exit
                 cur_exit = finite_dir ? fminf(fminf(fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny)), fmaf(pfz, iz, cnz)) : NEG_INF;
+                uint32_t n_entries = aux;
+                if constexpr (PRODUCT) {
+                    // The product needs EXACTLY the leaves the reference's walk reaches.  A child's box lies inside its parent's
+                    // (octree.rs:81-92: min or min + len/2, max or max - len/2) and BBox::intersects is monotone in the box when no
+                    // slab distance is a NaN (rounding of (bound - o) * inv is monotone in bound; bbox.rs:99-165 only compares near
+                    // with far distances), so for a ray with a finite inverse direction a leaf is reached iff ITS OWN box passes:
+                    // interior nodes are descended on the widened f32 test alone, and the exact decision is taken here, once per
+                    // leaf: shrunk box passed => reached; otherwise the reference's f64 test on the leaf's stored box.  The root
+                    // is never tested (octree.rs:149,177).
+                    if (cur != 0u && aux != 0u &&
+                        !surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
+                                    fmaf(pfz, iz, cnz))) {
+                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + cur);
+                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                        double tn, tf;
+                        if (!slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf)) n_entries = 0u;
+                    }
+                }
                 e_cur = link;
-                e_end = link + aux;
-                if (aux == 0u) last_exit = cur_exit;
+                e_end = link + n_entries;
+                if (n_entries == 0u) last_exit = cur_exit;
             }
         }
         // ---- phase 2: the leaf's entries, until it is finished or the lane's buffer is full.  The walk is bound by
@@ -806,7 +795,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     }
     hit->t = best_t;
     hit->ref = best_ref;
-    if (PRODUCT) *prod = acc;
+    if (PRODUCT) { *prod = acc; *fallback = fb; }
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 }
 
@@ -1348,8 +1337,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {
         Hit hit;
         V3 pr = v3(0, 0, 0);
-        traverse_ww<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit, &pr);
+        bool fb = false;
+        traverse_ww<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit, &pr, &fb);
         if (valid) v = pr;
+        if (valid && fb) {   // axis-parallel feeler: the all-f64 restatement of the reference's walk
+            Hit h2;
+            traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, distance_to_light, &h2, &v);
+        }
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if (valid) {
         Hit hit;

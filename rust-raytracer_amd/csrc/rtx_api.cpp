@@ -738,7 +738,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     std::vector<DWideChild> wide;
     RtxWideStats wstats;
     rtx_build_wide_bvh(pboxes, centre, wide, &wstats);
-    const bool wide_ok = 2 * wstats.depth + 2 <= 32 && wstats.nodes < (1 << 26);   // k_shadow_coop's level stack, queue entry bits
+    // k_shadow_coop's level stack (24 levels), queue entry bits, 23-bit prim index of a waiting pair
+    const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 26) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
     // images -> one RGBA8 atlas
     std::vector<DImage> images((size_t)d->n_images);
     std::vector<uint8_t> atlas;

@@ -1383,15 +1383,23 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
 // renderer.rs:212), so the per-ray answer is the exact any-hit answer.  A beam test is interval
 // arithmetic, hence conservative; an axis on which the group's directions change sign is left
 // unconstrained.
-#define RTX_COOP_STACK 64     // words: 32 spilled levels of 2 words (host checks 2 * depth + 2 <= 32)
-#define RTX_COOP_QUEUE 48     // RTX_COOP_QT - 1 + 2 * 16 at most
+#define RTX_COOP_STACK 48     // words: 24 spilled levels of 2 words (host checks 2 * depth + 2 <= 24)
+#define RTX_COOP_QUEUE 40     // RTX_COOP_QT - 1 + 2 * 16 at most
 #ifndef RTX_COOP_QT
 #define RTX_COOP_QT 6      // drain the candidate queue once it holds this many primitives
 #endif
 #ifndef RTX_COOP_WAVES
-#define RTX_COOP_WAVES 5
+#define RTX_COOP_WAVES 6     // one hit point per group: 80 VGPRs (5 spilled around the exact tests) and 26 KB of LDS; 194.8 against 198.5 ms at 5
+#endif
+#ifndef RTX_COOP_WAVES_MULTI
+#define RTX_COOP_WAVES_MULTI 5   // several hit points per group: 16 spills at 6 (sibenik frame 12.7 -> 14.0 ms)
 #endif
 #define RTX_COOP_PAIRS 128    // 63 waiting + 64 pushed in one step at most
+static_assert(RTX_COOP_QT - 1 + 32 <= RTX_COOP_QUEUE, "primitive queue too small for the drain threshold");
+// a waiting pair in one word: prim kind (2 bits) | owner lane and surely_in (7 bits) | prim index (23 bits: the host keeps scenes with
+// 2^23 triangles or spheres or more off this kernel)
+#define RTX_PAIR_INDEX 0x007FFFFFu
+DEV uint32_t pair_pack(uint32_t pref, uint32_t powner) { return (pref & RTX_WREF_KIND) | ((powner & 127u) << 23) | (pref & RTX_PAIR_INDEX); }
 #ifndef RTX_COOP_PT
 #define RTX_COOP_PT 1         // after a queue drain, run the exact tests once this many pairs wait
 #endif
@@ -1447,7 +1455,7 @@ DEV float grp_max(float v) {
 #define RTX_COOP_WIDE 0.02f   // largest spread of a group's hit points, as a fraction of the scene's radius
 #endif
 template <bool MULTI>
-__global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
+__global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
                                                                             uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
                                                                             DCounters *counters, double *acc) {
     // group-shared LDS, written and read by lanes of ONE wave: the LDS executes a wave's operations in
@@ -1457,18 +1465,23 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     __shared__ uint32_t s_queue[RTX_BLOCK / 16][RTX_COOP_QUEUE];
     // wave-shared: (primitive ref, owner lane | surely_in << 6) pairs that passed the owner's f32 box test and
     // wait for the exact f64 tests; s_hit[lane] != 0 once an exact test has found an occluder for that lane's ray
-    __shared__ uint2 s_pair[RTX_BLOCK / 64][RTX_COOP_PAIRS];
+    __shared__ uint32_t s_pair[RTX_BLOCK / 64][RTX_COOP_PAIRS];
     __shared__ uint32_t s_hit[RTX_BLOCK];
     // every lane's feeler (origin, direction, inverse direction), read back by the lane that runs its exact tests
     __shared__ double s_ray[3][RTX_BLOCK];      // direction per lane (the inverse is recomputed where an exact entry-bbox test needs it)
     // every lane's f32 traversal constants, read by whichever lanes test a queued primitive's box against this lane's ray:
-    // (ix, iy, iz, tmax_own | cnx, cny, cnz, - | cfx, cfy, cfz, -)
-    __shared__ float4 s_rayf[3][MULTI ? 1 : RTX_BLOCK];   // MULTI drains row by row, every lane its own ray
+    // (ix, iy, iz, tmax_own | cnx, cny, cnz, cfx) + (cfy, cfz)
+    __shared__ float4 s_rayf[2][MULTI ? 1 : RTX_BLOCK];   // MULTI drains row by row, every lane its own ray
+    __shared__ float2 s_rayg[MULTI ? 1 : RTX_BLOCK];
     __shared__ double s_org[3][MULTI ? RTX_BLOCK : RTX_BLOCK / 16];   // origin: per group (one hit point), or per lane
     // each group's beam (11 floats), re-read at every node step: they would otherwise sit in registers during the
     // exact tests, where the pressure peaks, and be spilled to scratch memory
     __shared__ float s_beam[RTX_BLOCK / 16][12];
 #define COOP_FENCE() asm volatile("" ::: "memory")
+#ifdef RTX_COOP_LDS_PAD
+    __shared__ uint32_t s_pad[RTX_COOP_LDS_PAD];   // experiment: fewer workgroups per CU, so that another kernel's workgroups fit next to them
+    if (n_groups == 0xFFFFFFFFu) s_pad[threadIdx.x] = tries;
+#endif
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
     bool valid = group < n_groups;
@@ -1674,8 +1687,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
     s_ray[0][threadIdx.x] = r.dx; s_ray[1][threadIdx.x] = r.dy; s_ray[2][threadIdx.x] = r.dz;
     if constexpr (!MULTI) {
         s_rayf[0][threadIdx.x] = make_float4(ix, iy, iz, tmax_own);
-        s_rayf[1][threadIdx.x] = make_float4(cnx, cny, cnz, 0.0f);
-        s_rayf[2][threadIdx.x] = make_float4(cfx, cfy, cfz, 0.0f);
+        s_rayf[1][threadIdx.x] = make_float4(cnx, cny, cnz, cfx);
+        s_rayg[threadIdx.x] = make_float2(cfy, cfz);
     }
     COOP_FENCE();
 #ifdef RTX_COUNT_LOOPS
@@ -1688,7 +1701,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
 #endif
         pair_n -= n;
         const bool mine = lane < n;
-        const uint2 pr = s_pair[wid][pair_n + (mine ? lane : 0u)];
+        const uint32_t pw = s_pair[wid][pair_n + (mine ? lane : 0u)];
+        const uint2 pr = make_uint2((pw & RTX_WREF_KIND) | (pw & RTX_PAIR_INDEX), (pw >> 23) & 127u);
         const uint32_t owner = (threadIdx.x & ~63u) + (pr.y & 63u);
         const double q_dist = __shfl(distance_to_light, (int)(pr.y & 63u));
         if (mine && s_hit[owner] == 0u) {
@@ -1816,7 +1830,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                         const uint32_t ol = (g << 4) | l16;               // the ray's lane in the wave
                         const uint32_t ot = (threadIdx.x & ~63u) + ol;    // ... and in the workgroup
                         if (s_hit[ot] == 0u) {
-                            const float4 ra = s_rayf[0][ot], rn = s_rayf[1][ot], rf = s_rayf[2][ot];
+                            const float4 ra = s_rayf[0][ot], rn = s_rayf[1][ot];
+                            const float2 rg = s_rayg[ot];
+                            const float4 rf = make_float4(rn.w, rg.x, rg.y, 0.0f);
                             const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
                             const float4 c_lo = pc[0], c_hi = pc[1];
                             const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
@@ -1844,7 +1860,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                     }
                     const unsigned long long pm = __ballot(push);
                     if (pm != 0ull) {
-                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(pref, powner);
+                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = pair_pack(pref, powner);
                         pair_n += (uint32_t)__popcll(pm);
                         COOP_FENCE();
                         if (pair_n >= 64u) run_pairs();
@@ -1888,7 +1904,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_COOP_WAVES) k_shadow_coop(DScen
                     }
                     const unsigned long long pm = __ballot(push);
                     if (pm != 0ull) {
-                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(pref, powner);
+                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = pair_pack(pref, powner);
                         pair_n += (uint32_t)__popcll(pm);
                         COOP_FENCE();
                         if (pair_n >= 64u) run_pairs();

@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 // writes the winning t and primitive ref per ray.  Kept apart from the shading so that the
 // traversal runs at its own (higher) occupancy.
 #ifndef RTX_CLOSEST_WAVES
-#define RTX_CLOSEST_WAVES 5
+#define RTX_CLOSEST_WAVES 6
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
@@ -1286,7 +1286,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
 // `tries` feelers of one (hit, light) pair sit in adjacent lanes and are reduced with
 // cross-lane shuffles before ONE set of atomics per group.
 #ifndef RTX_SHADOW_WAVES
-#define RTX_SHADOW_WAVES 1
+#define RTX_SHADOW_WAVES 6
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,

@@ -13,8 +13,14 @@ d, workload, l_shadow, l_closest, tag = sys.argv[1], sys.argv[2], float(sys.argv
 def load(db):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     c = sqlite3.connect(db)
-    for name, cname, val in c.execute("select kernel_name, counter_name, value from counters_collection"):
-        agg[name.split("(")[0].split()[-1].split("<")[0]][cname] += float(val)
+    seen = set()
+    for name, did, cname, val, start, end in c.execute(
+            "select kernel_name, dispatch_id, counter_name, value, start, end from counters_collection"):
+        k = name.split("(")[0].split()[-1].split("<")[0]
+        agg[k][cname] += float(val)
+        if did not in seen:   # the profiler serialises the dispatches of a --pmc pass: this is the kernel alone
+            seen.add(did)
+            agg[k]["_seconds"] += (int(end) - int(start)) * 1e-9
     return agg
 
 
@@ -32,7 +38,10 @@ def valu(k):
             "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64),
             "valu_insts_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
             "waves_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-            "l2_hit_rate": 1.0 - w[k]["TCC_MISS_sum"] / w[k]["TCC_REQ_sum"]}
+            "l2_hit_rate": 1.0 - w[k]["TCC_MISS_sum"] / w[k]["TCC_REQ_sum"],
+            # L2 -> CU: 128-byte requests served by the L2 per second of the kernel running alone
+            "l2_request_gbs": w[k]["TCC_REQ_sum"] * 128 / w[k]["_seconds"] / 1e9,
+            "hbm_gbs_alone": (f[k]["FETCH_SIZE"] * 2 + w[k]["WRITE_SIZE"]) * 1024 / w[k]["_seconds"] / 1e9}
 
 
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")

@@ -241,10 +241,10 @@ def test_pool_exhaustion_is_an_error_and_leaves_the_handle_usable(rtx):
     assert (np.abs(good.astype(int) - again.astype(int)) <= 1).all() and (good != again).mean() < 1e-3
 
 
-@pytest.mark.parametrize("tries", [1, 2, 4, 8, 16, 32, 3])
+@pytest.mark.parametrize("tries", [1, 2, 4, 8, 16, 32, 64, 48, 3])
 def test_cooperative_shadows_equal_per_lane_shadows(rtx, tries):
     """The cooperative 16-lane box-list traversal and the per-lane octree walk are two exact any-hit
-    searches over the same primitives: for every group size the images must be identical.  16 and 32 tries:
+    searches over the same primitives: for every group size the images must be identical.  16, 32, 48 and 64 tries:
     one hit point per group; 4 and 8: groups of neighbouring hit points, the compact ones walked cooperatively
     and the rest left to the per-lane kernel; 1, 2 and 3 (not a power of two): per-lane only."""
     flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32)

@@ -275,6 +275,12 @@ rtx_status rtx_nearest_hits(rtx_scene *scene, int64_t n, const double *origin, c
  * is the product of transmission() over all occluders, duplicates included. */
 rtx_status rtx_shadow_products(rtx_scene *scene, int64_t n, const double *origin, const double *target,
                                double *shadow_out);
+/* Same fold (renderer.rs:203-217 over the candidates of octree.rs:145-189).  flags = 0: the walk the renderer runs per
+ * feeler in scenes with transmissive materials (f32-classified boxes, exact decision per leaf, mailbox of known
+ * misses; what rtx_shadow_products calls); RTX_FLAG_REFERENCE_ORDER: the all-f64 restatement of the reference's walk.
+ * The parity tests compare the two with each other and with the oracle, ray by ray. */
+rtx_status rtx_shadow_products_ex(rtx_scene *scene, int64_t n, const double *origin, const double *target,
+                                  double *shadow_out, uint32_t flags);
 
 /* Diagnostic, needs no device: the octree rtx_scene_create builds for `desc` (Octree::from_iter,
  * octree.rs:15-43), dumped in DFS pre-order with children 0..7: per node 6 doubles (bbox min,

@@ -873,6 +873,11 @@ rtx_status rtx_nearest_hits(rtx_scene *s, int64_t n, const double *origin, const
 }
 
 rtx_status rtx_shadow_products(rtx_scene *s, int64_t n, const double *origin, const double *target, double *shadow_out) {
+    return rtx_shadow_products_ex(s, n, origin, target, shadow_out, 0);
+}
+
+rtx_status rtx_shadow_products_ex(rtx_scene *s, int64_t n, const double *origin, const double *target, double *shadow_out,
+                                  uint32_t flags) {
     if (!s || n < 0 || (n && (!origin || !target || !shadow_out))) return fail(RTX_ERR_INVALID_ARGUMENT, "bad argument");
     if (n == 0) return RTX_OK;
     HIPCHECK(hipSetDevice(s->device));
@@ -887,7 +892,7 @@ rtx_status rtx_shadow_products(rtx_scene *s, int64_t n, const double *origin, co
     if (hipMemcpy(d_o, origin, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_s, target, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(RTX_ERR_HIP, "upload failed"));
-    rtxk_shadow_products(nullptr, s->d, n, d_o, d_s, d_out);
+    rtxk_shadow_products(nullptr, s->d, n, d_o, d_s, d_out, flags);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return done(fail(RTX_ERR_HIP, "k_shadow_products failed"));
     if (hipMemcpy(shadow_out, d_out, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess)
         return done(fail(RTX_ERR_HIP, "download failed"));

@@ -185,4 +185,4 @@ void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint
 void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *direction,
                   int32_t *prim_id, double *t_out, uint32_t flags);
 void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
-                          double *out);
+                          double *out, uint32_t flags);

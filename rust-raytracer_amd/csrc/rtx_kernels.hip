@@ -2030,17 +2030,27 @@ template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_t n, const double *origin, const double *target,
                                                                 double *out) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_PRODUCT_FAST ? RTX_CAND_WORDS : 1];
     init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (gid >= n) return;
-    V3 p = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
-    V3 s = v3(target[gid * 3], target[gid * 3 + 1], target[gid * 3 + 2]);
+    if (MODE != MODE_PRODUCT_FAST && gid >= n) return;
+    const bool act = gid < n;   // MODE_PRODUCT_FAST: every lane of the wave takes part in the while-while walk
+    const int64_t g = act ? gid : 0;
+    V3 p = v3(origin[g * 3], origin[g * 3 + 1], origin[g * 3 + 2]);
+    V3 s = v3(target[g * 3], target[g * 3 + 1], target[g * 3 + 2]);
     V3 l = unit(s - p);
     Ray r = make_ray(p, l);
     double dist = len(s - p);
     Hit hit;
-    V3 v;
-    traverse<MODE>(sc, r, s_stk, EPSILON, dist, &hit, &v);
+    V3 v = v3(0, 0, 0);
+    if constexpr (MODE == MODE_PRODUCT_FAST) {   // what k_shadow<MODE_PRODUCT_FAST> runs per feeler
+        bool fb = false;
+        traverse_ww<WW_PRODUCT>(sc, r, act, s_stk, s_cand, EPSILON, dist, &hit, &v, &fb);
+        if (act && fb) traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, dist, &hit, &v);
+    } else {
+        traverse<MODE>(sc, r, s_stk, EPSILON, dist, &hit, &v);
+    }
+    if (!act) return;
     out[gid * 3] = v.x; out[gid * 3 + 1] = v.y; out[gid * 3 + 2] = v.z;
 }
 
@@ -2111,9 +2121,13 @@ void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double
                            direction, prim_id, t_out);
 }
 void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
-                          double *out) {
+                          double *out, uint32_t flags) {
     if (n <= 0) return;
     // always the multiset product here: with all-opaque scenes it equals the any-hit answer
-    hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
-                       origin, target, out);
+    if (flags & RTX_FLAG_REFERENCE_ORDER)
+        hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
+                           origin, target, out);
+    else
+        hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT_FAST>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc,
+                           n, origin, target, out);
 }

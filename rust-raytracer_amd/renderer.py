@@ -69,13 +69,14 @@ class Scene:
                   "rtx_nearest_hits")
         return pid, t
 
-    def shadow_products(self, origin, target):
+    def shadow_products(self, origin, target, flags=0):
+        """rtx_shadow_products_ex: flags 0 = the renderer's product walk, FLAG_REFERENCE_ORDER = the all-f64 walk."""
         o = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)
         s = np.ascontiguousarray(target, dtype=np.float64).reshape(-1, 3)
         out = np.zeros_like(o)
-        abi.check(self._lib.rtx_shadow_products(self.h, o.shape[0], o.ctypes.data_as(C.c_void_p),
-                                                s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
-                  "rtx_shadow_products")
+        abi.check(self._lib.rtx_shadow_products_ex(self.h, o.shape[0], o.ctypes.data_as(C.c_void_p),
+                                                   s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), flags),
+                  "rtx_shadow_products_ex")
         return out
 
 

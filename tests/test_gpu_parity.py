@@ -79,6 +79,46 @@ def test_shadow_products_match(rtx, orc, which):
     assert np.array_equal(got == 0.0, want == 0.0)
 
 
+@pytest.mark.parametrize("which", ["mesh_transmissive", "cornell", "cube"])
+def test_shadow_product_walks_agree_on_adversarial_feelers(rtx, orc, which):
+    """The renderer's product walk decides "reached or not" once per leaf, from the leaf's own box (nested boxes + monotone slab
+    test), and skips known misses through a mailbox; the all-f64 walk tests every child box like the reference.  Both must
+    give the same product ray by ray, also where the f32 classification cannot decide: feelers that start on faces, edges
+    and corners of octree cells, run along cell faces or exactly parallel to an axis (0 * inf slab distances: these take the
+    all-f64 path), or graze cell corners; and both must agree with the oracle."""
+    flat, cam_fn = _scene(rtx, which)
+    depth, bbox, shape, entries = rtx.octree_dump(flat)
+    rng = np.random.RandomState(17)
+    boxes = bbox[rng.randint(0, bbox.shape[0], size=1500)]
+    lo, hi = boxes[:, :3], boxes[:, 3:]
+    def on_cell(n):   # points on cell faces / edges / corners: each coordinate is min, max, mid or free
+        k = rng.randint(0, 4, size=(n, 3))
+        u = rng.uniform(size=(n, 3))
+        b = boxes[rng.randint(0, boxes.shape[0], size=n)]
+        l_, h_ = b[:, :3], b[:, 3:]
+        return np.where(k == 0, l_, np.where(k == 1, h_, np.where(k == 2, 0.5 * (l_ + h_), l_ + u * (h_ - l_))))
+    n = 6000
+    o = on_cell(n)
+    t = on_cell(n)
+    ax = rng.randint(0, 3, size=n)
+    par = rng.uniform(size=n) < 0.3          # exactly axis-parallel: the target differs in one coordinate only
+    step = (rng.uniform(0.5, 3.0, size=n) * (hi - lo).max()) * rng.choice([-1.0, 1.0], size=n)
+    t_par = o.copy()
+    t_par[np.arange(n), ax] += step
+    t = np.where(par[:, None], t_par, t)
+    keep = np.linalg.norm(t - o, axis=1) > 0
+    o, t = o[keep], t[keep]
+    sc = rtx.Scene(flat)
+    fast = sc.shadow_products(o, t)
+    exact = sc.shadow_products(o, t, flags=rtx.abi.FLAG_REFERENCE_ORDER)
+    sc.close()
+    want = orc.Scene(flat).shadow_products(o, t)
+    assert o.shape[0] > 4000
+    assert np.array_equal(fast == 0.0, exact == 0.0) and np.allclose(fast, exact, rtol=1e-15, atol=0.0)
+    assert np.array_equal(exact == 0.0, want == 0.0) and np.allclose(exact, want, rtol=1e-15, atol=0.0)
+    assert (fast != 1.0).any() and (fast == 1.0).any()
+
+
 def _compare(rgba, ids, orgba, oids, id_bar=0.9999, rgb_bar=0.999):
     id_ok = (ids == oids).mean()
     diff = np.abs(rgba[..., :3].astype(np.int32) - orgba[..., :3].astype(np.int32)).max(axis=-1)

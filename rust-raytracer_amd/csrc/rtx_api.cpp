@@ -848,6 +848,11 @@ rtx_status rtx_render(rtx_scene *s, const rtx_camera *cam, const rtx_options *op
 
 rtx_status rtx_nearest_hits(rtx_scene *s, int64_t n, const double *origin, const double *direction, int32_t *prim_id_out,
                             double *t_out) {
+    return rtx_nearest_hits_ex(s, n, origin, direction, prim_id_out, t_out, 0);
+}
+
+rtx_status rtx_nearest_hits_ex(rtx_scene *s, int64_t n, const double *origin, const double *direction, int32_t *prim_id_out,
+                               double *t_out, uint32_t flags) {
     if (!s || n < 0 || (n && (!origin || !direction || !prim_id_out || !t_out))) return fail(RTX_ERR_INVALID_ARGUMENT, "bad argument");
     if (n == 0) return RTX_OK;
     HIPCHECK(hipSetDevice(s->device));
@@ -864,7 +869,7 @@ rtx_status rtx_nearest_hits(rtx_scene *s, int64_t n, const double *origin, const
     if (hipMemcpy(d_o, origin, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_d, direction, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(RTX_ERR_HIP, "upload failed"));
-    rtxk_nearest(nullptr, s->d, n, d_o, d_d, d_id, d_t, 0);
+    rtxk_nearest(nullptr, s->d, n, d_o, d_d, d_id, d_t, flags);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return done(fail(RTX_ERR_HIP, "k_nearest failed"));
     if (hipMemcpy(prim_id_out, d_id, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(t_out, d_t, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)

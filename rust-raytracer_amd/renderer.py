@@ -58,15 +58,16 @@ class Scene:
                                               C.byref(st) if want_stats else None), "rtx_render_device")
         return st
 
-    def nearest_hits(self, origin, direction):
+    def nearest_hits(self, origin, direction, flags=0):
+        """rtx_nearest_hits_ex: flags 0 = the renderer's closest-hit walk, FLAG_REFERENCE_ORDER = the all-f64 walk."""
         o = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)
         d = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
         n = o.shape[0]
         pid = np.zeros(n, dtype=np.int32)
         t = np.zeros(n, dtype=np.float64)
-        abi.check(self._lib.rtx_nearest_hits(self.h, n, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
-                                             pid.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)),
-                  "rtx_nearest_hits")
+        abi.check(self._lib.rtx_nearest_hits_ex(self.h, n, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                                pid.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), flags),
+                  "rtx_nearest_hits_ex")
         return pid, t
 
     def shadow_products(self, origin, target, flags=0):

@@ -273,9 +273,11 @@ void free_work(Work &w) {
     if (w.sq.f) hipFree(w.sq.f);
     if (w.sq.key) hipFree(w.sq.key);
     if (w.sq.sample) hipFree(w.sq.sample);
+    if (w.sq.retry) hipFree(w.sq.retry);
     if (w.sq2.f) hipFree(w.sq2.f);
     if (w.sq2.key) hipFree(w.sq2.key);
     if (w.sq2.sample) hipFree(w.sq2.sample);
+    if (w.sq2.retry) hipFree(w.sq2.retry);
     for (hipStream_t a : w.aux)
         if (a) hipStreamDestroy(a);
     if (w.d_counters) hipFree(w.d_counters);
@@ -305,19 +307,21 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     }
     size_t nl = std::max<size_t>(s->lights.size(), 1);
     if (w.sq.cap < batch) {
-        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); w.sq = DShadowQ(); }
+        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); uint32_t *keep = w.sq.retry; w.sq = DShadowQ(); w.sq.retry = keep; }
         rtx_status st;
         if ((st = dev_alloc(&w.sq.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.key, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.sample, nl * (size_t)batch))) return st;
+        if (!w.sq.retry && (st = dev_alloc(&w.sq.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         w.sq.cap = batch;
     }
     if (w.sq2.cap < batch) {
-        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); w.sq2 = DShadowQ(); }
+        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); uint32_t *keep = w.sq2.retry; w.sq2 = DShadowQ(); w.sq2.retry = keep; }
         rtx_status st;
         if ((st = dev_alloc(&w.sq2.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.key, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.sample, nl * (size_t)batch))) return st;
+        if (!w.sq2.retry && (st = dev_alloc(&w.sq2.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         w.sq2.cap = batch;
     }
     for (hipStream_t &a : w.aux)

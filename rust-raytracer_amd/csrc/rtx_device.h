@@ -154,8 +154,11 @@ struct DShadowQ {
     double *f;          // [n_lights][6][cap]
     uint64_t *key;      // [n_lights][cap]
     uint32_t *sample;   // [n_lights][cap]
+    uint32_t *retry;    // [n_lights][2 + 2 * RTX_RETRY_CAP]: count, pad, then (feeler index, primary sample) pairs: the degenerate feelers
+                        // of the light's launch, answered by k_shadow_retry with the all-f64 walk
     uint32_t cap;
 };
+#define RTX_RETRY_CAP (1u << 20)
 
 struct DCounters {
     uint32_t pool_tail;

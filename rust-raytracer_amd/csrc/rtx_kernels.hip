@@ -263,6 +263,14 @@ struct Hit {
 #endif
 constexpr int REF_NONE = (int)0x80000000;
 constexpr int REF_PLANE = 0x40000000;
+constexpr int REF_RETRY = (int)0x80000001;   // k_closest -> k_closest_retry: this ray takes the all-f64 walk
+// DEGENERATE rays: a direction component that is zero or tiny.  Such a ray can lie in a face plane of an octree cell, where the
+// reference's own walk loses subtrees: with a zero component and the origin exactly on a node plane BBox::intersects computes
+// 0 * inf = NaN and rejects the box (bbox.rs:124-164: a NaN near distance fails the final `t_min < inf`), and within an ulp of a cell
+// face the f64 test of the very cell that lists the hit prim can fail.  The conservative f32 walks would reach those leaves and return
+// the nearer hit: right geometry, not the reference's answer.  These rays therefore go through the all-f64 restatement of the
+// reference's walk (k_closest_retry, k_shadow_retry), which is valid for every ray; the threshold only decides how many take it.
+DEV bool degenerate_dir(double dx, double dy, double dz) { return !(fabs(dx) >= 1.0e-9 && fabs(dy) >= 1.0e-9 && fabs(dz) >= 1.0e-9); }
 
 template <int MODE>
 DEV void traverse_exact(const DScene &sc, const Ray &r, uint32_t *stk /* LDS, stride RTX_BLOCK */, double t_lo, double t_hi,
@@ -1060,7 +1068,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene
         const double *f = pool.f + slot;
         Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
                       : make_ray(v3(0, 0, 0), v3(0, 0, 1));
-        traverse_ww<WW_CLOSEST>(sc, r, valid, s_stk, s_cand, T_MIN, inf(), &hit);
+        const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
+        traverse_ww<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit);
+        if (degen) hit.ref = REF_RETRY;
     } else if (valid) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
@@ -1072,6 +1082,38 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene
     if (gid < count) {
         hit_t[gid] = hit.t;
         hit_ref[gid] = valid ? hit.ref : REF_NONE;
+    }
+}
+
+// The all-f64 walk in the reference's visitation order for the rays k_closest<MODE_CLOSEST> has marked REF_RETRY (degenerate_dir).
+__global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool pool, uint32_t begin, uint32_t count, double *hit_t,
+                                                             int32_t *hit_ref) {
+    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    const bool mine = gid < count && hit_ref[gid] == REF_RETRY;
+    if (!__syncthreads_or(mine ? 1 : 0)) return;   // nearly every block
+    init_lds(s_stk);
+    if (!mine) return;
+    const size_t cap = pool.cap;
+    const double *f = pool.f + begin + gid;
+    const Ray r = make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]));
+    Hit hit;
+    V3 unused;
+    traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    hit_t[gid] = hit.t;
+    hit_ref[gid] = hit.ref;
+}
+
+// A degenerate shadow feeler (degenerate_dir) is left out of the any-hit kernels' sums and appended to the launch's retry list:
+// (feeler index = group * tries + k, primary sample); k_shadow_retry answers it with the all-f64 walk.
+DEV void retry_append(const DShadowQ &sq, uint32_t light, uint32_t feeler, uint32_t sample, DCounters *counters) {
+    uint32_t *list = sq.retry + (size_t)light * (2u + 2u * RTX_RETRY_CAP);
+    const uint32_t pos = atomicAdd(list, 1u);
+    if (pos < RTX_RETRY_CAP) {
+        list[2u + 2u * pos] = feeler;
+        list[3u + 2u * pos] = sample;
+    } else {
+        counters->overflow = 1u;   // the render fails with RTX_ERR_QUEUE_OVERFLOW rather than drop a feeler
     }
 }
 
@@ -1331,8 +1373,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
     if constexpr (MODE == MODE_ANY) {
         // every lane of the wave takes part in the while-while walk (its flushes are wave-wide)
         Hit hit;
-        traverse_ww<WW_ANY>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit);
-        if (valid) v = hit.ref == REF_NONE ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+        const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_shadow_retry; counts as 0 here
+        traverse_ww<WW_ANY>(sc, r, valid && !degen, s_stk, s_cand, EPSILON, distance_to_light, &hit);
+        if (valid) v = (hit.ref == REF_NONE && !degen) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+        if (degen) retry_append(sq, light, (uint32_t)gid, sample, counters);
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {
         Hit hit;
@@ -1367,6 +1411,39 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
         }
         if (valid && k == 0u) acc_add(acc, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
     } else if (valid) {
+        acc_add(acc, sample, w * scale(v, inv_tries));
+    }
+}
+
+// The retry list of one any-hit shadow launch (degenerate feelers, see degenerate_dir): each feeler is rebuilt exactly as k_shadow
+// builds it and answered by the all-f64 restatement of the reference's walk; its share of the group's average is added on its own
+// (the sum over the tries is linear).  A small fixed grid: the list is almost always empty.
+__global__ void __launch_bounds__(RTX_BLOCK) k_shadow_retry(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t tries, double *acc) {
+    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
+    const uint32_t *list = sq.retry + (size_t)light * (2u + 2u * RTX_RETRY_CAP);
+    uint32_t n = list[0];
+    if (n == 0u) return;
+    if (n > RTX_RETRY_CAP) n = RTX_RETRY_CAP;
+    init_lds(s_stk);
+    const size_t qc = sq.cap;
+    const double inv_tries = 1.0 / (double)tries;
+    for (uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x; i < n; i += gridDim.x * RTX_BLOCK) {
+        const uint32_t feeler = list[2u + 2u * i], sample = list[3u + 2u * i];
+        const uint32_t group = feeler / tries, k = feeler % tries;
+        const double *f = sq.f + (size_t)light * 6 * qc + group;
+        const V3 hp = v3(f[0 * qc], f[1 * qc], f[2 * qc]), w = v3(f[3 * qc], f[4 * qc], f[5 * qc]);
+        const uint64_t key = sq.key[(size_t)light * qc + group];
+        const rtx_light &lt = sc.lights[light];
+        V3 sampled = v3(lt.position[0], lt.position[1], lt.position[2]);
+        if (lt.kind != RTX_LIGHT_POINT) {                                                // spherelight.rs:13-23
+            double ux, uy, uz;
+            draw3(fr.rng_mode, key, STREAM_LIGHT, light, k, &ux, &uy, &uz);
+            sampled = sampled + v3(lt.radius * (ux - 0.5), lt.radius * (uy - 0.5), lt.radius * (uz - 0.5));
+        }
+        const Ray r = make_ray(hp, unit(sampled - hp));
+        Hit hit;
+        V3 v;
+        traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, len(sampled - hp), &hit, &v);
         acc_add(acc, sample, w * scale(v, inv_tries));
     }
 }
@@ -1534,7 +1611,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     const float tmax_own = f32_above(distance_to_light - tsh);
     // a feeler that misses the scene's cube (or ends before reaching it) has no finite candidate: it takes no
     // part in the beam and in the per-ray tests
-    const bool walk = valid && !re.miss && distance_to_light >= tsh;
+    const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_shadow_retry; counts as 0 here
+    const bool walk = valid && !degen && !re.miss && distance_to_light >= tsh;
 
     // ---- the group's beam, as a frustum along its dominant axis a0 (the axis with the largest
     // |direction| that every ray of the group travels in the same sense).  With u = distance along
@@ -1581,6 +1659,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         const float spread = fmaxf(fmaxf(o0max - o0min, o1max - o1min), o2max - o2min);   // NaN / -inf (no walker): not wide
         wide = !beam_ok || spread > RTX_COOP_WIDE * (float)sc.radius;
     }
+    if (degen && !wide) retry_append(sq, light, (uint32_t)gid, sample, counters);   // (a wide group is left to k_shadow<MODE_ANY>, which appends)
     // 1 / |d0| = |1 / d0|: the ray's own inverse direction (make_ray), no second division
     const double inv0 = fabs(a0 == 0 ? r.ix : (a0 == 1 ? r.iy : r.iz));
     grp_min_max(walk ? f32_below(d1 * inv0) : INF, walk ? f32_above(d1 * inv0) : -INF, &m1L, &m1H);
@@ -1616,7 +1695,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
 #define COOP_QUE(i) s_queue[sub][(i)]
     const uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t below = (1u << l16) - 1u;
-    bool alive = valid;     // the feeler has met no occluder yet
+    bool alive = valid && !degen;     // the feeler has met no occluder yet
     bool seek = walk && !wide;   // ... and can still meet a finite one (a wide group does not walk at all)
     uint32_t a16 = (uint32_t)(__ballot(seek) >> gbase) & 0xFFFFu;
     // Group state, replicated in every lane of the group (it is computed from ballots only).
@@ -2015,8 +2094,13 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
     Ray r = make_ray(o, d);
     Hit hit;
     V3 unused;
-    if constexpr (MODE == MODE_CLOSEST) traverse_ww<WW_CLOSEST>(sc, r, true, s_stk, s_cand, T_MIN, inf(), &hit);
-    else traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
+    if constexpr (MODE == MODE_CLOSEST) {   // what k_closest + k_closest_retry do
+        const bool degen = degenerate_dir(r.dx, r.dy, r.dz);
+        traverse_ww<WW_CLOSEST>(sc, r, !degen, s_stk, s_cand, T_MIN, inf(), &hit);
+        if (degen) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    } else {
+        traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
+    }
     int pid = -1;
     if (hit.ref != REF_NONE) {
         if (hit.ref >= 0 && !(hit.ref & REF_PLANE)) pid = sc.tris[hit.ref].prim_id;
@@ -2069,8 +2153,12 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
         hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
                            count, counters, hit_t, hit_ref);
     else
+    {
         hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
                            counters, hit_t, hit_ref);
+        hipLaunchKernelGGL(k_closest_retry, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
+                           hit_ref);
+    }
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
     hipLaunchKernelGGL(k_shade, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t, hit_ref,
@@ -2085,6 +2173,8 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
     // wide (a ground plane seen near the horizon) and walk most of the hierarchy
     const bool coop = sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP);
+    const bool any_hit = sc.all_opaque != 0;   // the any-hit kernels hand degenerate feelers to k_shadow_retry
+    if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * RTX_RETRY_CAP), 0, sizeof(uint32_t), (hipStream_t)stream);
     if (coop && tries % 16u == 0u) {        // the 16 lanes of a group = feelers of one hit point
         hipLaunchKernelGGL(k_shadow_coop<false>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
@@ -2104,6 +2194,8 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     else
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_FAST>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
+    if (any_hit)
+        hipLaunchKernelGGL(k_shadow_retry, dim3(64), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, tries, acc);
 }
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out) {
     uint64_t n_pix = (uint64_t)fr.n_blocks_local * fr.tiles_x * 64u;

@@ -179,3 +179,35 @@ def kitchen_sink_scene(rtx, lights="mixed"):
     b.background = (0.05, 0.07, 0.12)
     cam = lambda w, h, fov=35.0: rtx.camera((0, 10, 140), (0, 0, 0), (0, 1, 0), fov, w, h)
     return b.build(), cam
+
+
+def axis_aligned_scene(rtx):
+    """Everything on integer coordinates and aligned with the axes: a tessellated floor, two boxes, a point light and a camera
+    that looks straight down from above the centre.  With an odd image width the centre column of primary rays has a direction
+    component that is exactly zero and origins on octree planes; its hit points share a coordinate with the light, so their
+    shadow feelers are degenerate too, and the mirror-like floor sends reflection rays straight back up."""
+    b = rtx.SceneBuilder()
+    b.point_light((0, 6, 1), (1.0, 0.9, 0.8))
+    b.sphere_light((2, 7, 0), (0.3, 0.3, 0.5), 1.0)
+    floor = b.cook_torrance(k_a=0.1, k_d=0.6, k_s=0.4, k_sg=0.4, gauss_constant=5.0, roughness=0.1, ior=1.3, diffuse=(0.7, 0.7, 0.7))
+    box = b.cook_torrance(k_a=0.1, k_d=0.7, k_s=0.3, k_sg=0.2, gauss_constant=5.0, roughness=0.2, ior=1.3, diffuse=(0.8, 0.3, 0.2))
+    tris = []
+    for i in range(-4, 4):
+        for j in range(-4, 4):
+            a, bb, c, d = (i, 0, j), (i + 1, 0, j), (i + 1, 0, j + 1), (i, 0, j + 1)
+            tris += [(a, c, bb), (a, d, c)]
+    b.triangles(np.array(tris, dtype=np.float64), floor)
+    def cuboid(lo, hi):
+        x0, y0, z0 = lo
+        x1, y1, z1 = hi
+        v = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+        q = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (3, 2, 6, 7), (4, 5, 1, 0)]
+        out = []
+        for a, bb, c, d in q:
+            out += [(v[a], v[bb], v[c]), (v[a], v[c], v[d])]
+        return np.array(out, dtype=np.float64)
+    b.triangles(cuboid((-1, 0, -1), (1, 2, 0)), box)      # straddles x = 0, ends at z = 0
+    b.triangles(cuboid((2, 0, 1), (3, 1, 3)), box)
+    b.background = (0.2, 0.3, 0.4)
+    cam = lambda w, h, fov=25.0: rtx.camera((0, 10, 0), (0, 0, 0), (0, 0, -1), fov, w, h)
+    return b.build(), cam

@@ -59,6 +59,29 @@ def test_nearest_hits_bit_exact(rtx, orc, which):
     assert np.array_equal(t.view(np.uint64), ot.view(np.uint64))
 
 
+@pytest.mark.parametrize("size", [(65, 64), (64, 64), (33, 40)])
+def test_axis_aligned_scene_parity(rtx, orc, size):
+    """A scene on integer coordinates seen straight from above: with an odd width the centre column of primary rays, its
+    reflections and its shadow feelers towards a light that shares their x have a direction component that is exactly zero, and
+    start on octree planes: the rays for which the reference's own walk loses subtrees (NaN slab distances).  They go through
+    k_closest_retry / k_shadow_retry, and the frame must still match the oracle: prim ids everywhere, colours to +-1."""
+    flat, cam_fn = scenes.axis_aligned_scene(rtx)
+    cam = cam_fn(*size)
+    sc = rtx.Scene(flat)
+    assert sc.info().all_opaque == 1
+    opt = rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=1, pixel_samples=1, rng_mode=0)
+    rgba, ids, st = sc.render(cam, opt)
+    rgba2, ids2, _ = sc.render(cam, rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=1, rng_mode=0))
+    sc.close()
+    osc = orc.Scene(flat)
+    orgba, oids, _ = osc.render(cam, opt)
+    orgba2, oids2, _ = osc.render(cam, rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=1, rng_mode=0))
+    assert (ids >= 0).mean() > 0.5
+    assert np.array_equal(ids, oids) and np.array_equal(ids2, oids2)
+    assert (np.abs(rgba[..., :3].astype(int) - orgba[..., :3].astype(int)) <= 1).all()
+    assert (np.abs(rgba2[..., :3].astype(int) - orgba2[..., :3].astype(int)) <= 1).all()      # 16 tries: the cooperative kernel
+
+
 def _cell_points(rtx, flat, rng, n):
     """Points on faces / edges / corners of octree cells: each coordinate is a cell's min, max, mid or free inside it."""
     depth, bbox, shape, entries = rtx.octree_dump(flat)
@@ -99,10 +122,8 @@ def test_nearest_hits_on_degenerate_rays(rtx, orc, which):
     sc.close()
     assert (opid >= 0).sum() > 100
     assert np.array_equal(rpid, opid) and np.array_equal(rt.view(np.uint64), ot.view(np.uint64))
-    assert (tt <= ot).all()
-    differs = tt.view(np.uint64) != ot.view(np.uint64)
-    assert (np.abs(d[differs]).min(axis=1) < 1e-12).all()
-    same_t = ~differs
+    assert np.array_equal(tt.view(np.uint64), ot.view(np.uint64))   # degenerate rays take the all-f64 walk (k_closest_retry)
+    same_t = np.ones(len(tt), dtype=bool)
     # exact ties in t between prims that share an edge or a vertex (these rays aim at cell corners, which in the cube scene
     # are the cube's own vertices): the near-to-far walk may meet the other prim first
     assert (pid[same_t] != opid[same_t]).mean() <= 0.05

@@ -269,9 +269,10 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_camera *camera, const r
  * Used by the parity tests to compare hit ids / t bit for bit with the oracle. */
 rtx_status rtx_nearest_hits(rtx_scene *scene, int64_t n, const double *origin, const double *direction,
                             int32_t *prim_id_out, double *t_out);
-/* Same query (ray.rs:44-66).  flags = 0: the renderer's closest-hit walk (what rtx_nearest_hits calls);
- * RTX_FLAG_REFERENCE_ORDER: the all-f64 restatement in the reference's visitation order, which also reproduces what the
- * reference's walk does to rays that lie in a face plane of an octree cell ("degenerate rays"). */
+/* Same query (ray.rs:44-66).  flags = 0: what the renderer does per ray (what rtx_nearest_hits calls): the conservative
+ * f32 walk with exact f64 tests, and for rays with a direction component below 1e-9 the all-f64 walk (they can lie in a face
+ * plane of an octree cell, where the reference's own walk loses subtrees: DESIGN.md, "Degenerate rays");
+ * RTX_FLAG_REFERENCE_ORDER: the all-f64 restatement in the reference's visitation order for every ray. */
 rtx_status rtx_nearest_hits_ex(rtx_scene *scene, int64_t n, const double *origin, const double *direction,
                                int32_t *prim_id_out, double *t_out, uint32_t flags);
 

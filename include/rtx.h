@@ -211,7 +211,9 @@ typedef struct rtx_stats {
      * -DRTX_COUNT_WORK (librtx_count.so, profiling only): [0] closest-hit rays, [1] shadow
      * feelers; nodes visited, leaf entries fetched, primitive tests run */
     uint64_t work[2][3];
-    uint64_t reserved[2];
+    uint64_t exact_shadow_rerenders;   /* 1 if a shadow launch met more degenerate feelers than its retry list holds and the frame
+                                          was therefore rendered again with all-f64 shadow walks ("Degenerate rays") */
+    uint64_t reserved[1];
 } rtx_stats;
 
 typedef struct rtx_scene_info {

@@ -99,7 +99,8 @@ class Stats(C.Structure):
         ("ms_total", C.c_double), ("ms_device", C.c_double),
         ("ms_closest", C.c_double), ("ms_shadow", C.c_double),
         ("launches_closest", C.c_uint32), ("launches_shadow", C.c_uint32),
-        ("peak_pool_rays", C.c_uint64), ("work", (C.c_uint64 * 3) * 2), ("reserved", C.c_uint64 * 2),
+        ("peak_pool_rays", C.c_uint64), ("work", (C.c_uint64 * 3) * 2), ("exact_shadow_rerenders", C.c_uint64),
+        ("reserved", C.c_uint64 * 1),
     ]
 
     @property

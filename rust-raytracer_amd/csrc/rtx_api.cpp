@@ -308,6 +308,7 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     size_t nl = std::max<size_t>(s->lights.size(), 1);
     if (w.sq.cap < batch) {
         if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); uint32_t *keep = w.sq.retry; w.sq = DShadowQ(); w.sq.retry = keep; }
+        w.sq.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.key, nl * (size_t)batch))) return st;
@@ -317,6 +318,7 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     }
     if (w.sq2.cap < batch) {
         if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); uint32_t *keep = w.sq2.retry; w.sq2 = DShadowQ(); w.sq2.retry = keep; }
+        w.sq2.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq2.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.key, nl * (size_t)batch))) return st;
@@ -375,19 +377,95 @@ struct Seg {
     uint32_t begin, end;
 };
 
-rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *d_rgba, int32_t *d_ids,
-                       hipStream_t stream, rtx_stats *stats) {
+// The device workspace of one render call: the scene handle's own buffers (ensure_work) or a carving of the static device
+// scratch (rtx_render_device_noalloc).
+struct WorkView {
+    DPool pool{};
+    DShadowQ sq{}, sq2{};
+    DCounters *d_counters = nullptr;
+    unsigned long long (*d_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr;
+    double *hit_t = nullptr;
+    int32_t *hit_ref = nullptr;
+    double *acc = nullptr;
+};
+
+// Ray pool sizing.  The pool is a stack of segments processed depth-first (deepest generation first, at most `batch` rays per
+// launch), so generation g holds at most batch * fanout rays and the live total is bounded by batch * (1 + fanout * levels),
+// levels = longest child chain.
+struct PoolNeed {
+    uint32_t fanout = 0, levels = 0;
+    uint64_t per_batch = 1;
+};
+PoolNeed pool_need(const rtx_scene *s, const rtx_options *opt);
+
+#define RTX_STATIC_MAX_SEGS 64   // segment stack of the allocation-free entry point (levels + 2 are needed)
+
+// Carves the static scratch into the workspace of one call; picks the batch (<= want_batch, a multiple of RTX_BLOCK) that fits.
+rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, const PoolNeed &need, uint32_t want_batch,
+                        WorkView &v, uint32_t *batch_out, uint32_t *pool_cap_out) {
+    const size_t nl = std::max<size_t>(n_lights, 1);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t fixed = up(sizeof(DCounters)) + up(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)) +
+                         up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 16 * 256 /* alignment of the arrays below */;
+    // per ray of a batch: hit record 12, pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8
+    const size_t pool_per = std::max<uint64_t>(need.per_batch, 1 + (uint64_t)need.fanout);
+    const size_t per = 12 + pool_per * 88 + nl * 60 + nl * 8;
+    if (fixed + per * RTX_BLOCK + nl * 8 > RTX_STATIC_SCRATCH_BYTES)
+        return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: this call needs " + std::to_string(fixed + per * RTX_BLOCK) +
+                                       " bytes of workspace, the static device scratch holds " + std::to_string(RTX_STATIC_SCRATCH_BYTES) +
+                                       " (render fewer samples per call: shard_index / shard_count, or use rtx_render_device)");
+    uint64_t batch = (RTX_STATIC_SCRATCH_BYTES - fixed - nl * 8) / per;
+    batch = std::min<uint64_t>(batch, want_batch ? want_batch : (1u << 20));
+    batch = std::max<uint64_t>(RTX_BLOCK, batch / RTX_BLOCK * RTX_BLOCK);
+    const uint64_t pool_cap = batch * pool_per;
+    uint8_t *p = base;
+    auto take = [&](size_t bytes) { uint8_t *q = p; p += up(bytes); return q; };
+    v.d_counters = (DCounters *)take(sizeof(DCounters));
+    v.d_ray_slots = (unsigned long long (*)[RTX_RAY_SLOT_WORDS])take(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long));
+    v.acc = (double *)take((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double));
+    v.hit_t = (double *)take(batch * sizeof(double));
+    v.hit_ref = (int32_t *)take(batch * sizeof(int32_t));
+    v.pool.f = (double *)take(pool_cap * 9 * sizeof(double));
+    v.pool.key = (uint64_t *)take(pool_cap * sizeof(uint64_t));
+    v.pool.sample = (uint32_t *)take(pool_cap * sizeof(uint32_t));
+    v.pool.flags = (uint32_t *)take(pool_cap * sizeof(uint32_t));
+    v.pool.cap = (uint32_t)pool_cap;
+    v.sq.f = (double *)take(nl * 6 * batch * sizeof(double));
+    v.sq.key = (uint64_t *)take(nl * batch * sizeof(uint64_t));
+    v.sq.sample = (uint32_t *)take(nl * batch * sizeof(uint32_t));
+    v.sq.retry_cap = (uint32_t)batch;
+    v.sq.retry = (uint32_t *)take(nl * (2 + 2 * batch) * sizeof(uint32_t));
+    v.sq.cap = (uint32_t)batch;
+    v.sq2 = v.sq;   // one launch after the other on the caller's stream: one queue is enough
+    if ((size_t)(p - base) > RTX_STATIC_SCRATCH_BYTES) return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: workspace layout exceeds the static scratch");
+    *batch_out = (uint32_t)batch;
+    *pool_cap_out = (uint32_t)pool_cap;
+    return RTX_OK;
+}
+
+PoolNeed pool_need(const rtx_scene *s, const rtx_options *opt) {
+    PoolNeed n;
+    if (s->any_reflective) {
+        n.fanout += s->any_glossy ? std::max<uint32_t>(1, opt->gloss_samples) : 1;
+        n.levels += opt->reflect_depth > 1 ? opt->reflect_depth - 1 : 0;
+    }
+    if (s->any_refractive) {
+        n.fanout += 1;
+        n.levels += opt->refract_depth > 1 ? opt->refract_depth - 1 : 0;
+    }
+    if (n.levels == 0) n.fanout = 0;
+    n.per_batch = 1 + (uint64_t)n.fanout * n.levels;
+    return n;
+}
+
+constexpr rtx_status RTX_INTERNAL_RETRY_OVERFLOW = -1;   // render_once -> render_impl: render the frame again with exact shadows
+
+// One frame.  `noalloc`: the allocation-free variant (rtx_render_device_noalloc): the workspace is the static device scratch, every
+// launch runs on the caller's stream, no events, no pinned host buffers, no host heap.
+rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint32_t extra_flags, uint8_t *d_rgba,
+                       int32_t *d_ids, hipStream_t stream, rtx_stats *stats, bool noalloc) {
     auto wall0 = std::chrono::steady_clock::now();
-    if (!s || !cam || !opt || !d_rgba) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (cam->image_width == 0 || cam->image_height == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "empty image");
-    if (cam->image_height % 8 != 0)
-        return fail(RTX_ERR_INVALID_ARGUMENT, "image_height must be a multiple of 8 (renderer.rs:73 underflows otherwise)");
-    if (opt->reflect_depth > RTX_MAX_DEPTH || opt->refract_depth > RTX_MAX_DEPTH)
-        return fail(RTX_ERR_LIMIT, "reflect_depth / refract_depth above 4095");
-    if (opt->rng_mode > RTX_RNG_PHILOX) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown rng_mode");
     uint32_t shard_count = opt->shard_count ? opt->shard_count : 1;
-    if (opt->shard_index >= shard_count) return fail(RTX_ERR_INVALID_ARGUMENT, "shard_index >= shard_count");
-    HIPCHECK(hipSetDevice(s->device));
 
     DFrame fr{};
     fill_camera(fr, *cam);
@@ -402,41 +480,42 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     fr.n_blocks_local = opt->shard_index < n_blocks ? (n_blocks - opt->shard_index + shard_count - 1) / shard_count : 0;
     fr.reflect_depth = opt->reflect_depth; fr.refract_depth = opt->refract_depth;
     fr.shadow_samples = opt->shadow_samples; fr.gloss_samples = opt->gloss_samples;
-    fr.rng_mode = opt->rng_mode; fr.frame = opt->frame; fr.flags = opt->flags;
+    fr.rng_mode = opt->rng_mode; fr.frame = opt->frame;
+    fr.flags = (opt->flags & RTX_FLAG_PUBLIC_MASK) | extra_flags | (noalloc ? (uint32_t)RTX_FLAG_SERIAL : 0u);
 
     uint64_t n_samples64 = (uint64_t)fr.n_blocks_local * fr.tiles_x * 64ull * fr.spp;
     if (n_samples64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "more than 2^32 samples in one call");
     uint32_t n_samples = (uint32_t)n_samples64;
 
-    // Ray pool sizing.  The pool is a stack of segments processed depth-first (deepest generation
-    // first, at most `batch` rays per launch), so generation g holds at most batch*fanout rays and
-    // the live total is bounded by batch * (1 + fanout * levels), levels = longest child chain.
-    uint32_t fanout = 0, levels = 0;
-    if (s->any_reflective) {
-        fanout += s->any_glossy ? std::max<uint32_t>(1, opt->gloss_samples) : 1;
-        levels += opt->reflect_depth > 1 ? opt->reflect_depth - 1 : 0;
-    }
-    if (s->any_refractive) {
-        fanout += 1;
-        levels += opt->refract_depth > 1 ? opt->refract_depth - 1 : 0;
-    }
-    if (levels == 0) fanout = 0;
-    uint64_t need_per_batch = 1 + (uint64_t)fanout * levels;
-    uint32_t batch = opt->batch_rays;
-    if (!batch) {   // default: 8 Mi rays per launch (measured: bunny 10.9 -> 9.9 ms against 4 Mi, sponza within 1 %), shrunk so that
-                    // the pool stays <= 64 Mi rays (5.6 GB)
-        uint64_t b = (64ull << 20) / need_per_batch;
-        batch = (uint32_t)std::min<uint64_t>(8u << 20, std::max<uint64_t>(b, 256u << 10));
-    }
-    batch = std::max<uint32_t>(batch, RTX_BLOCK);
-    uint64_t pool_cap64 = opt->pool_rays ? opt->pool_rays : (uint64_t)batch * need_per_batch;
-    pool_cap64 = std::max<uint64_t>(pool_cap64, (uint64_t)batch * (1 + fanout));
-    if (pool_cap64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "ray pool above 2^32 rays");
-    uint32_t pool_cap = (uint32_t)pool_cap64;
-
-    rtx_status st = ensure_work(s, pool_cap, batch, n_samples);
-    if (st) return st;
+    const PoolNeed need = pool_need(s, opt);
+    const uint32_t fanout = need.fanout;
+    uint32_t batch = opt->batch_rays, pool_cap = 0;
+    WorkView v;
     Work &w = s->w;
+    rtx_status st;
+    if (noalloc) {
+        if (need.levels + 2 > RTX_STATIC_MAX_SEGS)
+            return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: reflect_depth + refract_depth above 62");
+        int herr = 0;
+        uint8_t *base = (uint8_t *)rtxk_static_scratch(s->device, &herr);
+        if (!base) return fail(RTX_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)herr));
+        if ((st = carve_static(base, s->lights.size(), n_samples, need, opt->batch_rays, v, &batch, &pool_cap))) return st;
+    } else {
+        if (!batch) {   // default: 8 Mi rays per launch (measured: bunny 10.9 -> 9.9 ms against 4 Mi, sponza within 1 %), shrunk so that
+                        // the pool stays <= 64 Mi rays (5.6 GB)
+            uint64_t b = (64ull << 20) / need.per_batch;
+            batch = (uint32_t)std::min<uint64_t>(8u << 20, std::max<uint64_t>(b, 256u << 10));
+        }
+        batch = std::max<uint32_t>(batch, RTX_BLOCK);
+        uint64_t pool_cap64 = opt->pool_rays ? opt->pool_rays : (uint64_t)batch * need.per_batch;
+        pool_cap64 = std::max<uint64_t>(pool_cap64, (uint64_t)batch * (1 + fanout));
+        if (pool_cap64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "ray pool above 2^32 rays");
+        pool_cap = (uint32_t)pool_cap64;
+        if ((st = ensure_work(s, pool_cap, batch, n_samples))) return st;
+        v.pool = w.pool; v.sq = w.sq; v.sq2 = w.sq2; v.d_counters = w.d_counters; v.d_ray_slots = w.d_ray_slots;
+        v.hit_t = w.hit_t; v.hit_ref = w.hit_ref; v.acc = w.acc;
+    }
+
     size_t ev_used = 0;
     auto next_event = [&](hipEvent_t *e) -> rtx_status {
         if (ev_used == w.events.size()) {
@@ -449,16 +528,23 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     };
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
-    const bool timing = stats != nullptr;
+    const bool timing = stats != nullptr && !noalloc;
 
     // the depth test at the top of Renderer::trace (renderer.rs:106): no rays at all
     bool trace_anything = opt->reflect_depth > 0 && opt->refract_depth > 0 && fr.spp > 0;
+    // the any-hit shadow kernels keep a retry list per launch; its overflow flag is read once, after the last launch
+    const bool uses_retry = trace_anything && opt->shadow_samples > 0 && !s->lights.empty() && s->d.all_opaque &&
+                            !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS);
 
-    if (n_samples) HIPCHECK(hipMemsetAsync(w.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));
-    std::memset(w.h_up, 0, sizeof(DCounters));
-    w.h_up->ray_slots = w.d_ray_slots;
-    HIPCHECK(hipMemsetAsync(w.d_ray_slots, 0, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), stream));
-    HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, sizeof(DCounters), hipMemcpyHostToDevice, stream));
+    if (n_samples) HIPCHECK(hipMemsetAsync(v.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));
+    HIPCHECK(hipMemsetAsync(v.d_ray_slots, 0, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), stream));
+    if (noalloc) {
+        rtxk_init_counters(stream, v.d_counters, v.d_ray_slots);   // no pinned staging buffer in this variant: a one-thread kernel
+    } else {
+        std::memset(w.h_up, 0, sizeof(DCounters));
+        w.h_up->ray_slots = v.d_ray_slots;
+        HIPCHECK(hipMemcpyAsync(v.d_counters, w.h_up, sizeof(DCounters), hipMemcpyHostToDevice, stream));
+    }
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     if (timing) {
         if ((st = next_event(&ev_first))) return st;
@@ -467,49 +553,66 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
 
     uint32_t launches_closest = 0, launches_shadow = 0;
     uint64_t peak_pool = 0;
-    std::vector<Seg> segs;
+    Seg seg_fixed[RTX_STATIC_MAX_SEGS];
+    std::vector<Seg> seg_heap;
+    size_t n_segs = 0;
+    auto seg_push = [&](Seg sg) {
+        if (noalloc) seg_fixed[n_segs] = sg;   // bounded by levels + 2 <= RTX_STATIC_MAX_SEGS (checked above)
+        else if (n_segs < seg_heap.size()) seg_heap[n_segs] = sg;
+        else seg_heap.push_back(sg);
+        ++n_segs;
+    };
+    auto seg_top = [&]() -> Seg & { return noalloc ? seg_fixed[n_segs - 1] : seg_heap[n_segs - 1]; };
     uint32_t s_next = 0;
     // Streams: the closest-hit / shade chain runs on the caller's stream, the shadow launches of a step on
     // w.aux[light % 2], so that they overlap each other and the NEXT step's closest-hit launch (a closest-hit launch ends in a long tail of
     // few waves, a small one is nothing but tail; the shadow kernels only read their queue and add to `acc` with
     // atomics).  Two shadow queues alternate: k_shade of step i waits until the shadow launches of step i - 2 have
     // read theirs.  The caller's stream joins w.aux[] before the resolve.
-    const bool overlap = !(opt->flags & RTX_FLAG_SERIAL) && opt->shadow_samples > 0 && !s->lights.empty();
+    const bool overlap = !(fr.flags & RTX_FLAG_SERIAL) && opt->shadow_samples > 0 && !s->lights.empty();
     hipEvent_t sq_free[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [queue][aux stream]
     const size_t n_aux = std::min<size_t>(2, s->lights.size());
     uint32_t step = 0;
-    auto bail = [&](rtx_status e) {   // leave nothing running on the library's own stream
+    // Every failure after the first launch leaves through here: nothing keeps running on the library's own streams (they read
+    // the shadow queues and add to `acc`, which the caller may free or render into again as soon as this call has returned).
+    auto bail = [&](rtx_status e) {
         if (overlap)
             for (hipStream_t a : w.aux) hipStreamSynchronize(a);
+        hipStreamSynchronize(stream);
         return e;
     };
-    while (trace_anything) {
-        if (segs.empty()) {
-            if (s_next >= n_samples) break;
+    uint32_t back_tail = 0, back_overflow = 0;
+    // one wavefront step; a non-zero status is returned through bail()
+    auto one_step = [&]() -> rtx_status {
+        if (n_segs == 0) {
             uint32_t cnt = std::min<uint32_t>(batch, n_samples - s_next);
-            rtxk_generate(stream, fr, w.pool, 0, s_next, cnt);
-            segs.push_back(Seg{0, cnt});
+            rtxk_generate(stream, fr, v.pool, 0, s_next, cnt);
+            seg_push(Seg{0, cnt});
             s_next += cnt;
         }
-        Seg &top = segs.back();
+        Seg &top = seg_top();
         uint32_t top_end = top.end;
         uint32_t n = std::min<uint32_t>(batch, top.end - top.begin);
         if (fanout > 0) {
             uint64_t fit = (uint64_t)(pool_cap - top_end) / fanout;
             if (fit < n) n = (uint32_t)fit;
-            if (n == 0) return bail(fail(RTX_ERR_QUEUE_OVERFLOW, "ray pool exhausted; raise rtx_options.pool_rays"));
+            if (n == 0) return fail(RTX_ERR_QUEUE_OVERFLOW, "ray pool exhausted; raise rtx_options.pool_rays");
         }
         uint32_t begin = top.end - n;
-        w.h_up->pool_tail = top_end;
-        w.h_up->overflow = 0;
-        HIPCHECK(hipMemcpyAsync(w.d_counters, w.h_up, offsetof(DCounters, ray_slots), hipMemcpyHostToDevice, stream));
+        if (noalloc) {
+            rtxk_set_pool_tail(stream, v.d_counters, top_end);
+        } else {
+            w.h_up->pool_tail = top_end;
+            w.h_up->overflow = 0;
+            HIPCHECK(hipMemcpyAsync(v.d_counters, w.h_up, offsetof(DCounters, ray_slots), hipMemcpyHostToDevice, stream));
+        }
         Span sp_c{nullptr, nullptr, 0};
         if (timing) {
             if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b))) return st;
             HIPCHECK(hipEventRecord(sp_c.a, stream));
         }
-        const DShadowQ &sq = (overlap && (step & 1u)) ? w.sq2 : w.sq;
-        rtxk_trace(stream, s->d, fr, w.pool, begin, n, sq, w.d_counters, w.acc, d_ids, w.hit_t, w.hit_ref,
+        const DShadowQ &sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
+        rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
                    overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr);
         ++launches_closest;
         if (timing) {
@@ -518,12 +621,14 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         }
         // the counters travel back while the shadow kernels run: the host only needs them (children
         // spawned, overflow) to size the NEXT closest-hit launch
-        HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
         hipEvent_t ev_back = nullptr;
-        if (overlap) {
-            if ((st = next_event(&ev_back))) return bail(st);
-            HIPCHECK(hipEventRecord(ev_back, stream));
-            for (size_t a = 0; a < n_aux; ++a) HIPCHECK(hipStreamWaitEvent(w.aux[a], ev_back, 0));
+        if (!noalloc) {
+            HIPCHECK(hipMemcpyAsync(w.h_back, v.d_counters, offsetof(DCounters, ray_slots), hipMemcpyDeviceToHost, stream));
+            if (overlap) {
+                if ((st = next_event(&ev_back))) return st;
+                HIPCHECK(hipEventRecord(ev_back, stream));
+                for (size_t a = 0; a < n_aux; ++a) HIPCHECK(hipStreamWaitEvent(w.aux[a], ev_back, 0));
+            }
         }
         // shadow groups sit at their ray's index (empty where the ray hit nothing): n groups per light
         if (opt->shadow_samples > 0) {
@@ -535,7 +640,7 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                     if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
                     HIPCHECK(hipEventRecord(sp_s.a, sstream));
                 }
-                rtxk_shadow(sstream, s->d, fr, sq, (uint32_t)li, n, tries, w.d_counters, w.acc);
+                rtxk_shadow(sstream, s->d, fr, sq, (uint32_t)li, n, tries, v.d_counters, v.acc);
                 ++launches_shadow;
                 if (timing) {
                     HIPCHECK(hipEventRecord(sp_s.b, sstream));
@@ -543,62 +648,110 @@ rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                 }
             }
         }
-        if (overlap) {
+        if (noalloc) {
+            uint32_t two[2] = {0, 0};   // pool_tail, overflow: a blocking 8-byte copy into pageable memory
+            HIPCHECK(hipMemcpyAsync(two, v.d_counters, sizeof(two), hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            back_tail = two[0]; back_overflow = two[1];
+        } else if (overlap) {
             for (size_t a = 0; a < n_aux; ++a) {
-                if (!sq_free[step & 1u][a] && (st = next_event(&sq_free[step & 1u][a]))) return bail(st);
+                if (!sq_free[step & 1u][a] && (st = next_event(&sq_free[step & 1u][a]))) return st;
                 HIPCHECK(hipEventRecord(sq_free[step & 1u][a], w.aux[a]));
             }
             HIPCHECK(hipEventSynchronize(ev_back));   // the counters are back; the shadow launches go on
+            back_tail = w.h_back->pool_tail; back_overflow = w.h_back->overflow;
         } else {
             HIPCHECK(hipStreamSynchronize(stream));
+            back_tail = w.h_back->pool_tail; back_overflow = w.h_back->overflow;
         }
         ++step;
-        if (w.h_back->overflow) return bail(fail(RTX_ERR_QUEUE_OVERFLOW, "device queue overflow"));
+        if (back_overflow) return fail(RTX_ERR_QUEUE_OVERFLOW, "device queue overflow");
         top.end = begin;
-        if (top.begin == top.end) segs.pop_back();
-        uint32_t children = w.h_back->pool_tail - top_end;
-        if (children) segs.push_back(Seg{top_end, top_end + children});
+        if (top.begin == top.end) --n_segs;
+        uint32_t children = back_tail - top_end;
+        if (children) seg_push(Seg{top_end, top_end + children});
         peak_pool = std::max<uint64_t>(peak_pool, (uint64_t)top_end + children);
-    }
-    if (overlap)
-        for (int i = 0; i < 2; ++i)
-            for (int a = 0; a < 2; ++a)
-                if (sq_free[i][a]) HIPCHECK(hipStreamWaitEvent(stream, sq_free[i][a], 0));
-    rtxk_resolve(stream, fr, w.acc, d_rgba);
-    HIPCHECK(hipGetLastError());
+        return RTX_OK;
+    };
+    while (trace_anything && (n_segs > 0 || s_next < n_samples))
+        if ((st = one_step())) return bail(st);
 
-    if (stats) {
-        if ((st = next_event(&ev_last))) return st;
-        HIPCHECK(hipEventRecord(ev_last, stream));
-        HIPCHECK(hipMemcpyAsync(w.h_back, w.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
-        HIPCHECK(hipMemcpyAsync(w.h_ray_slots, w.d_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    auto finish = [&]() -> rtx_status {
+        if (overlap)
+            for (int i = 0; i < 2; ++i)
+                for (int a = 0; a < 2; ++a)
+                    if (sq_free[i][a]) HIPCHECK(hipStreamWaitEvent(stream, sq_free[i][a], 0));
+        rtxk_resolve(stream, fr, v.acc, d_rgba);
+        HIPCHECK(hipGetLastError());
+        if (!stats && !uses_retry) return RTX_OK;   // nothing to read back: the call returns with the frame enqueued
+
+        unsigned long long slots_stack[RTX_RAY_SLOTS][RTX_RAY_SLOT_WORDS];   // 64 KB
+        unsigned long long (*h_slots)[RTX_RAY_SLOT_WORDS] = noalloc ? slots_stack : w.h_ray_slots;
+        DCounters back_stack;
+        DCounters *h_back = noalloc ? &back_stack : w.h_back;
+        if (timing) {
+            if ((st = next_event(&ev_last))) return st;
+            HIPCHECK(hipEventRecord(ev_last, stream));
+        }
+        HIPCHECK(hipMemcpyAsync(h_back, v.d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
+        if (stats)
+            HIPCHECK(hipMemcpyAsync(h_slots, v.d_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
+        if (uses_retry && h_back->retry_overflow) return RTX_INTERNAL_RETRY_OVERFLOW;
+        if (!stats) return RTX_OK;
         std::memset(stats, 0, sizeof(*stats));
         for (int sl = 0; sl < RTX_RAY_SLOTS; ++sl) {
-            stats->rays_primary += w.h_ray_slots[sl][RAY_PRIMARY];
-            stats->rays_reflect += w.h_ray_slots[sl][RAY_REFLECT];
-            stats->rays_gloss += w.h_ray_slots[sl][RAY_GLOSS];
-            stats->rays_refract += w.h_ray_slots[sl][RAY_REFRACT];
+            stats->rays_primary += h_slots[sl][RAY_PRIMARY];
+            stats->rays_reflect += h_slots[sl][RAY_REFLECT];
+            stats->rays_gloss += h_slots[sl][RAY_GLOSS];
+            stats->rays_refract += h_slots[sl][RAY_REFRACT];
             for (size_t li = 0; li < s->lights.size(); ++li) {   // shadow groups emitted per light x tries (renderer.rs:194-198)
                 uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;
-                stats->rays_shadow += w.h_ray_slots[sl][RTX_RAY_SLOT_GROUPS + li] * tries;
+                stats->rays_shadow += h_slots[sl][RTX_RAY_SLOT_GROUPS + li] * tries;
             }
         }
         for (int c = 0; c < 2; ++c)
-            for (int k = 0; k < 3; ++k) stats->work[c][k] = w.h_back->work[c][k];
-        float ms = 0.f;
-        HIPCHECK(hipEventElapsedTime(&ms, ev_first, ev_last));
-        stats->ms_device = ms;
-        for (const Span &sp : spans) {
-            HIPCHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
-            (sp.kind == 0 ? stats->ms_closest : stats->ms_shadow) += ms;
+            for (int k = 0; k < 3; ++k) stats->work[c][k] = h_back->work[c][k];
+        if (timing) {
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, ev_first, ev_last));
+            stats->ms_device = ms;
+            for (const Span &sp : spans) {
+                HIPCHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
+                (sp.kind == 0 ? stats->ms_closest : stats->ms_shadow) += ms;
+            }
         }
         stats->launches_closest = launches_closest;
         stats->launches_shadow = launches_shadow;
         stats->peak_pool_rays = peak_pool;
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    }
+        return RTX_OK;
+    };
+    if ((st = finish())) return bail(st);
     return RTX_OK;
+}
+
+rtx_status render_impl(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *d_rgba, int32_t *d_ids,
+                       hipStream_t stream, rtx_stats *stats, bool noalloc) {
+    if (!s || !cam || !opt || !d_rgba) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (cam->image_width == 0 || cam->image_height == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "empty image");
+    if (cam->image_height % 8 != 0)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "image_height must be a multiple of 8 (renderer.rs:73 underflows otherwise)");
+    if (opt->reflect_depth > RTX_MAX_DEPTH || opt->refract_depth > RTX_MAX_DEPTH)
+        return fail(RTX_ERR_LIMIT, "reflect_depth / refract_depth above 4095");
+    if (opt->rng_mode > RTX_RNG_PHILOX) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown rng_mode");
+    if (opt->flags & ~(uint32_t)RTX_FLAG_PUBLIC_MASK) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown bit in rtx_options.flags");
+    if (opt->shard_index >= (opt->shard_count ? opt->shard_count : 1)) return fail(RTX_ERR_INVALID_ARGUMENT, "shard_index >= shard_count");
+    HIPCHECK(hipSetDevice(s->device));
+    rtx_status st = render_once(s, cam, opt, 0u, d_rgba, d_ids, stream, stats, noalloc);
+    // A launch met more degenerate shadow feelers than its retry list holds (a light lying in the plane of a floor: every feeler from
+    // the floor has a zero direction component).  No feeler is dropped: the frame is rendered again with every shadow launch on the
+    // all-f64 restatement of the reference's walk, which needs no retry list.  Slow, and only for such scenes.
+    if (st == RTX_INTERNAL_RETRY_OVERFLOW) {
+        st = render_once(s, cam, opt, RTX_FLAG_INTERNAL_EXACT_SHADOWS, d_rgba, d_ids, stream, stats, noalloc);
+        if (st == RTX_OK && stats) stats->exact_shadow_rerenders = 1;
+    }
+    return st;
 }
 
 } // namespace
@@ -819,7 +972,7 @@ rtx_status rtx_scene_get_info(const rtx_scene *s, rtx_scene_info *info) {
 
 rtx_status rtx_render_device(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, void *rgba_out_dev,
                              void *primary_prim_id_out_dev, void *stream, rtx_stats *stats) {
-    return render_impl(s, cam, opt, (uint8_t *)rgba_out_dev, (int32_t *)primary_prim_id_out_dev, (hipStream_t)stream, stats);
+    return render_impl(s, cam, opt, (uint8_t *)rgba_out_dev, (int32_t *)primary_prim_id_out_dev, (hipStream_t)stream, stats, false);
 }
 
 rtx_status rtx_render(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *rgba_out,
@@ -836,7 +989,7 @@ rtx_status rtx_render(rtx_scene *s, const rtx_camera *cam, const rtx_options *op
         if ((st = dev_alloc(&w.out_rgba, n_pix * 4)) || (st = dev_alloc(&w.out_ids, n_pix))) return st;
         w.out_pixels = n_pix;
     }
-    rtx_status st = render_impl(s, cam, opt, w.out_rgba, primary_prim_id_out ? w.out_ids : nullptr, nullptr, stats);
+    rtx_status st = render_impl(s, cam, opt, w.out_rgba, primary_prim_id_out ? w.out_ids : nullptr, nullptr, stats, false);
     if (st) return st;
     HIPCHECK(hipDeviceSynchronize());
     uint32_t shard_count = opt->shard_count ? opt->shard_count : 1;

@@ -154,11 +154,17 @@ struct DShadowQ {
     double *f;          // [n_lights][6][cap]
     uint64_t *key;      // [n_lights][cap]
     uint32_t *sample;   // [n_lights][cap]
-    uint32_t *retry;    // [n_lights][2 + 2 * RTX_RETRY_CAP]: count, pad, then (feeler index, primary sample) pairs: the degenerate feelers
+    uint32_t *retry;    // [n_lights][2 + 2 * retry_cap]: count, pad, then (feeler index, primary sample) pairs: the degenerate feelers
                         // of the light's launch, answered by k_shadow_retry with the all-f64 walk
     uint32_t cap;
+    uint32_t retry_cap; // pairs per light (RTX_RETRY_CAP in the library's own workspace, smaller in the static one)
 };
 #define RTX_RETRY_CAP (1u << 20)
+// internal bit of DFrame.flags (never accepted from rtx_options.flags): every shadow launch runs the all-f64 restatement of the
+// reference's walk (k_shadow<MODE_PRODUCT>), which is valid for every feeler of every scene.  Set for the re-render of a frame
+// whose retry list overflowed (more degenerate feelers in one launch than the list holds).
+#define RTX_FLAG_INTERNAL_EXACT_SHADOWS 0x80000000u
+#define RTX_FLAG_PUBLIC_MASK 0x7u
 
 struct DCounters {
     uint32_t pool_tail;
@@ -172,6 +178,11 @@ struct DCounters {
     // builds with -DRTX_COUNT_WORK only (librtx_count.so): [0] closest-hit rays, [1] shadow feelers;
     // nodes visited, leaf entries fetched, prim tests run
     unsigned long long work[2][3];
+    // set by the any-hit shadow kernels when a launch's retry list is full.  It lies behind `ray_slots`, so the per-step upload
+    // of (pool_tail, overflow) never clears it while shadow launches of an earlier step are still running; the host reads it
+    // once, after the frame's last shadow launch.
+    uint32_t retry_overflow;
+    uint32_t pad_;
 };
 
 // ---- launch wrappers implemented in rtx_kernels.hip (all enqueue on `stream`) -----------
@@ -189,3 +200,13 @@ void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double
                   int32_t *prim_id, double *t_out, uint32_t flags);
 void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
                           double *out, uint32_t flags);
+// sets counters->pool_tail, clears counters->overflow (a one-thread kernel: the allocation-free entry point has no pinned
+// host buffer to copy them from)
+void rtxk_set_pool_tail(rtx_stream_t stream, DCounters *counters, uint32_t pool_tail);
+// zeroes the whole record and sets its ray_slots pointer (same reason)
+void rtxk_init_counters(rtx_stream_t stream, DCounters *counters, unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS]);
+// The static device scratch of rtx_render_device_noalloc: a file-scope __device__ array in rtx_kernels.hip.  Resolves (once per
+// device, with that device current) and returns the array's address ON `device`; NULL + a hipError_t code on failure.
+#define RTX_STATIC_SCRATCH_BYTES (32u << 20)
+#define RTX_MAX_DEVICES 64
+void *rtxk_static_scratch(int device, int *hip_error);

@@ -1107,13 +1107,15 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool po
 // A degenerate shadow feeler (degenerate_dir) is left out of the any-hit kernels' sums and appended to the launch's retry list:
 // (feeler index = group * tries + k, primary sample); k_shadow_retry answers it with the all-f64 walk.
 DEV void retry_append(const DShadowQ &sq, uint32_t light, uint32_t feeler, uint32_t sample, DCounters *counters) {
-    uint32_t *list = sq.retry + (size_t)light * (2u + 2u * RTX_RETRY_CAP);
+    uint32_t *list = sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap);
     const uint32_t pos = atomicAdd(list, 1u);
-    if (pos < RTX_RETRY_CAP) {
+    if (pos < sq.retry_cap) {
         list[2u + 2u * pos] = feeler;
         list[3u + 2u * pos] = sample;
     } else {
-        counters->overflow = 1u;   // the render fails with RTX_ERR_QUEUE_OVERFLOW rather than drop a feeler
+        // no feeler is dropped silently: the host reads this flag after the frame's last shadow launch and renders the frame
+        // again with every shadow launch on the all-f64 walk (RTX_FLAG_INTERNAL_EXACT_SHADOWS)
+        counters->retry_overflow = 1u;
     }
 }
 
@@ -1420,10 +1422,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
 // (the sum over the tries is linear).  A small fixed grid: the list is almost always empty.
 __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_retry(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t tries, double *acc) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    const uint32_t *list = sq.retry + (size_t)light * (2u + 2u * RTX_RETRY_CAP);
+    const uint32_t *list = sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap);
     uint32_t n = list[0];
     if (n == 0u) return;
-    if (n > RTX_RETRY_CAP) n = RTX_RETRY_CAP;
+    if (n > sq.retry_cap) n = sq.retry_cap;   // overflow: counters->retry_overflow is set and the host renders the frame again
     init_lds(s_stk);
     const size_t qc = sq.cap;
     const double inv_tries = 1.0 / (double)tries;
@@ -2172,10 +2174,14 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
     // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
     // wide (a ground plane seen near the horizon) and walk most of the hierarchy
-    const bool coop = sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP);
-    const bool any_hit = sc.all_opaque != 0;   // the any-hit kernels hand degenerate feelers to k_shadow_retry
-    if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * RTX_RETRY_CAP), 0, sizeof(uint32_t), (hipStream_t)stream);
-    if (coop && tries % 16u == 0u) {        // the 16 lanes of a group = feelers of one hit point
+    const bool exact = (fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) != 0u;   // re-render after a retry-list overflow
+    const bool coop = sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && !exact;
+    const bool any_hit = sc.all_opaque != 0 && !exact;   // the any-hit kernels hand degenerate feelers to k_shadow_retry
+    if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap), 0, sizeof(uint32_t), (hipStream_t)stream);
+    if (exact)   // the all-f64 product walk answers every feeler, degenerate or not (all-opaque scenes: a product of zeros)
+        hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+    else if (coop && tries % 16u == 0u) {        // the 16 lanes of a group = feelers of one hit point
         hipLaunchKernelGGL(k_shadow_coop<false>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     } else if (coop && (tries == 4u || tries == 8u)) {   // measured: with 1 try per hit point (16 origins per group) the per-lane walk wins
@@ -2197,6 +2203,50 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     if (any_hit)
         hipLaunchKernelGGL(k_shadow_retry, dim3(64), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, tries, acc);
 }
+__global__ void k_set_pool_tail(DCounters *counters, uint32_t pool_tail) {
+    counters->pool_tail = pool_tail;
+    counters->overflow = 0u;
+}
+__global__ void k_init_counters(DCounters *counters, unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS]) {
+    DCounters c = {};
+    c.ray_slots = ray_slots;
+    *counters = c;
+}
+void rtxk_init_counters(rtx_stream_t stream, DCounters *counters, unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS]) {
+    hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(1), 0, (hipStream_t)stream, counters, ray_slots);
+}
+void rtxk_set_pool_tail(rtx_stream_t stream, DCounters *counters, uint32_t pool_tail) {
+    hipLaunchKernelGGL(k_set_pool_tail, dim3(1), dim3(1), 0, (hipStream_t)stream, counters, pool_tail);
+}
+
+// The workspace of rtx_render_device_noalloc (rtx.h): ray pool, shadow queue, hit records, counters and sample accumulators of
+// ONE call at a time, carved out by the host (rtx_api.cpp).  Every GPU the library runs on holds its own copy of this array at its
+// own address until the process ends; the name below is a host-side stand-in, never a device address: host code uses the pointer
+// hipGetSymbolAddress returns for the CURRENT device, resolved once per device and kept.
+static __device__ __align__(256) unsigned char scratch[RTX_STATIC_SCRATCH_BYTES];
+static void *g_scratch_ptr[RTX_MAX_DEVICES];   // per device; NULL = not resolved yet
+
+void *rtxk_static_scratch(int device, int *hip_error) {
+    if (hip_error) *hip_error = (int)hipSuccess;
+    if (device < 0 || device >= RTX_MAX_DEVICES) {
+        if (hip_error) *hip_error = (int)hipErrorInvalidDevice;
+        return nullptr;
+    }
+    if (g_scratch_ptr[device]) return g_scratch_ptr[device];
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess && cur != device) e = hipSetDevice(device);   // the address belongs to the device that is current
+    void *ptr = nullptr;
+    if (e == hipSuccess) e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    if (e != hipSuccess || !ptr) {
+        if (hip_error) *hip_error = (int)(e != hipSuccess ? e : hipErrorInvalidSymbol);
+        return nullptr;
+    }
+    g_scratch_ptr[device] = ptr;
+    return ptr;
+}
+
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out) {
     uint64_t n_pix = (uint64_t)fr.n_blocks_local * fr.tiles_x * 64u;
     if (n_pix == 0) return;

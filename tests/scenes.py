@@ -93,10 +93,12 @@ def cornell_scene(rtx, glossy=False):
     return b.build(), cam
 
 
-def mesh_scene(rtx, n_u=24, n_v=16, skybox=True, transmissive=False, point_light=False):
+def mesh_scene(rtx, n_u=24, n_v=16, skybox=True, transmissive=False, point_light=False, third_light=False):
     """A bunny.rs-style scene: ground plane + two mirror spheres + a displaced-sphere mesh."""
     b = rtx.SceneBuilder()
     b.sphere_light((200, -200, 100), (1, 1, 1), 40.0)
+    if third_light:
+        b.sphere_light((60, -120, 220), (0.2, 0.3, 0.4), 25.0)
     if point_light:
         b.point_light((-95, 20, 170), (0.5, 0.5, 0.3))
     else:

@@ -1,0 +1,153 @@
+"""BASELINE.json's configs at the settings they are quoted on, against the CPU oracle (-m gpu).
+
+  C3 sponza  : pixel_samples 4 (16 spp), 16 shadow samples  -> test_gpu_parity.test_baseline_scenes_full_size_properties
+  C4 heptoroid-refractive : reflect / refract depth 16 (this file)
+  C5 sibenik : pixel_samples 2, 4 shadow samples, and frames of the 0-7 s camera animation (this file)
+
+and the error paths of the wavefront loop: a launch whose retry list overflows, a pool that runs out in mid-frame."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(rgba, ids, orgba, oids, id_bar=0.9999, rgb_bar=0.999):
+    id_ok = (ids == oids).mean()
+    diff = np.abs(rgba[..., :3].astype(np.int32) - orgba[..., :3].astype(np.int32)).max(axis=-1)
+    rgb_ok = (diff <= 1).mean()
+    assert id_ok >= id_bar, "prim-id parity %.6f" % id_ok
+    assert rgb_ok >= rgb_bar, "rgb +-1 parity %.6f (max diff %d)" % (rgb_ok, diff.max())
+    return id_ok, rgb_ok
+
+
+@pytest.mark.parametrize("detail,size", [(0.05, (32, 64)), (0.07, (8, 64))])
+def test_heptoroid_refractive_depth_16(rtx, orc, detail, size):
+    """BASELINE config 4 as stated: reflect_depth = refract_depth = 16 (renderer.rs:105-186 recursing 30 levels; k_sg = k_tg = 1,
+    ior 1.5, transmission 0.8: every hit spawns a mirror and a transmission child, the shadow product runs over the
+    multiset).  The ray tree grows ~x7 per two levels (one hit pixel of the detail-0.07 mesh spawns about 10^6 rays),
+    so the frame is tiny and tall (8-row tiles keep the oracle's threads busy).  Pool sizing at levels = 30
+    (need_per_batch = 61), the 12-bit depth counters of the ray flags and the segment stack are all in play; a second
+    render with a 4096-ray batch pushes the pool to its bound and the segment stack to its full depth."""
+    named = rtx.host.NamedScene("heptoroid-refractive", detail=detail)
+    cam = named.camera(size[0], size[1], 45.0)
+    kw = dict(reflect_depth=16, refract_depth=16, shadow_samples=1, pixel_samples=1, rng_mode=0)
+    orgba, oids, ocn = orc.Scene(named).render(cam, rtx.options(**kw), threads=16)
+    sc = rtx.Scene(named)
+    rgba, ids, st = sc.render(cam, rtx.options(**kw))
+    rgba2, ids2, st2 = sc.render(cam, rtx.options(batch_rays=4096, **kw))
+    sc.close()
+    assert (oids >= 0).sum() >= 5 and ocn.rays[3] > 100000
+    assert np.array_equal(ids, oids) and np.array_equal(ids2, oids)
+    # a handful of hit pixels, each the sum of ~10^5..10^6 paths: every one of them within +-1
+    assert (np.abs(rgba[..., :3].astype(int) - orgba[..., :3].astype(int)) <= 1).all()
+    assert (np.abs(rgba2[..., :3].astype(int) - orgba[..., :3].astype(int)) <= 1).all()
+    for got in (st, st2):   # identical ray accounting: 1 per get_nearest_hit, 1 per shadow try
+        assert (got.rays_primary, got.rays_reflect, got.rays_gloss, got.rays_refract, got.rays_shadow) == tuple(int(x) for x in ocn.rays[:5])
+    assert st2.launches_closest > st.launches_closest and st2.peak_pool_rays <= 4096 * 61
+
+
+def test_sibenik_at_config_settings(rtx, orc):
+    """BASELINE config 5's still settings (pixel_samples 2, 4 shadow samples, depth 3/3, three lights) at 1920x1080: the
+    whole frame through both shadow traversals and, on two 8-row blocks, against the oracle."""
+    named = rtx.host.NamedScene("sibenik")
+    cam = named.camera(1920, 1080, 45.0)
+    kw = dict(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=2, rng_mode=1, seed=0)
+    sc = rtx.Scene(named)
+    full, ids, st = sc.render(cam, rtx.options(**kw))
+    alt, ids2, _ = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_NO_COOP, **kw))
+    sc.close()
+    assert np.array_equal(ids, ids2)
+    assert (np.abs(full.astype(int) - alt.astype(int)) <= 1).all() and (full != alt).mean() < 1e-3
+    osc = orc.Scene(named)
+    for b in (30, 95):
+        o_rgba, o_ids, _ = osc.render(cam, rtx.options(**kw), threads=16, rows=(b * 8, b * 8 + 8))
+        rows = slice(b * 8, b * 8 + 8)
+        assert (ids[rows] == o_ids[rows]).mean() >= 0.9999
+        assert (np.abs(full[rows, :, :3].astype(int) - o_rgba[rows, :, :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
+
+
+@pytest.mark.parametrize("t", [0.0, 3.5, 7.0])
+def test_sibenik_animation_frames(rtx, orc, t):
+    """Frames of config 5's 0-7 s camera animation: the camera of time t comes out of the host mirror's Animator::lerp_camera
+    (animator.rs:44-48, 91-114: keyframe pair, Bezier easing, lerped position / look_at / up) and the frame
+    (frame number = floor(t * 25), part of the RNG key) is compared with the oracle's at that camera."""
+    named = rtx.host.NamedScene("sibenik", detail=0.5)
+    cam = named.camera(480, 272, 45.0, time=t)
+    still = named.camera(480, 272, 45.0)
+    if t > 0.0:
+        assert list(cam.position) != list(still.position)   # the camera does move
+    kw = dict(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=2, rng_mode=1, seed=0, frame=int(t * 25))
+    orgba, oids, ocn = orc.Scene(named).render(cam, rtx.options(**kw), threads=16)
+    sc = rtx.Scene(named)
+    rgba, ids, st = sc.render(cam, rtx.options(**kw))
+    sc.close()
+    _compare(rgba, ids, orgba, oids)
+    assert abs(int(st.rays_total) - int(ocn.rays_total)) <= 1e-3 * ocn.rays_total + 2
+
+
+def _floor_scene(rtx, n=24):
+    """A tessellated floor in the plane y = 0 under a POINT light that lies in that plane, and a box above it: every feeler
+    from a floor point has a y component of ~1e-16 / distance (the hit point's y is o + d * t rounding noise), i.e. is
+    degenerate (< 1e-9) and goes to the launch's retry list."""
+    b = rtx.SceneBuilder()
+    b.point_light((6.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    grey = b.cook_torrance(k_a=0.1, k_d=0.8, k_s=0.2, gauss_constant=5.0, roughness=0.2, ior=1.5, diffuse=(0.8, 0.8, 0.8))
+    xs = np.linspace(-8.0, 8.0, n + 1)
+    v = []
+    for i in range(n):
+        for j in range(n):
+            p00, p10 = (xs[i], 0.0, xs[j]), (xs[i + 1], 0.0, xs[j])
+            p01, p11 = (xs[i], 0.0, xs[j + 1]), (xs[i + 1], 0.0, xs[j + 1])
+            v += [(p00, p01, p11), (p00, p11, p10)]
+    # a small box standing on the floor between camera and light casts a shadow along the floor
+    c = [(x, y, z) for x in (1.0, 2.0) for y in (0.0, 1.5) for z in (-0.5, 0.5)]
+    for q in [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]:
+        v += [(c[q[0]], c[q[1]], c[q[2]]), (c[q[0]], c[q[2]], c[q[3]])]
+    b.triangles(np.array(v, dtype=np.float64), grey)
+    b.background = (0.1, 0.2, 0.3)
+    return b.build(), lambda w, h: rtx.camera((-3.0, 6.0, 7.0), (1.0, 0.0, 0.0), (0, 1, 0), 30.0, w, h)
+
+
+def test_retry_list_overflow_rerenders_with_exact_shadows(rtx, orc):
+    """More degenerate feelers in one shadow launch than its retry list holds (2^20 per light): no feeler is dropped and the
+    call does not fail; the library notices the overflow flag after the frame's last shadow launch and renders the frame
+    again with every shadow launch on the all-f64 restatement of the reference's walk.  The frame must match the
+    oracle; a frame with few degenerate feelers (same scene, small) takes the ordinary path and matches too."""
+    flat, cam_fn = _floor_scene(rtx)
+    osc = orc.Scene(flat)
+    sc = rtx.Scene(flat)
+    assert sc.info().all_opaque == 1
+    for size, ps in (((1280, 1024), 2), ((96, 64), 1)):   # 5.2 M primary samples, most of them on the floor / 6 k
+        cam = cam_fn(*size)
+        opt = rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=1, pixel_samples=ps, rng_mode=1, seed=4)
+        rgba, ids, st = sc.render(cam, opt)
+        rows = (size[1] // 4, 3 * size[1] // 4) if size[1] > 64 else (0, size[1])
+        orgba, oids, _ = osc.render(cam, opt, threads=16, rows=rows)
+        r = slice(*rows)
+        assert (ids[r] >= 0).mean() > 0.5
+        _compare(rgba[r], ids[r], orgba[r], oids[r])
+        assert st.rays_shadow > 0.5 * st.rays_primary
+        assert st.exact_shadow_rerenders == (1 if ps == 2 else 0)
+    sc.close()
+
+
+def test_mid_frame_failure_drains_and_handle_stays_usable(rtx):
+    """A pool that runs out on a LATER wavefront step, in a scene with three lights (both of the library's shadow streams are busy
+    when the step fails): the call returns RTX_ERR_QUEUE_OVERFLOW only after its launches have drained, and the very next
+    render on the same handle, into the same output array, is the correct frame."""
+    flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=True, third_light=True)
+    assert flat.n_lights == 3
+    cam = cam_fn(160, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=8, refract_depth=8, shadow_samples=2, pixel_samples=2, rng_mode=1, seed=3)
+    good, ids, st = sc.render(cam, rtx.options(**kw))
+    out = np.zeros_like(good)
+    with pytest.raises(rtx.abi.RtxError) as err:   # the first steps fit; the pool runs out once the segment stack has grown
+        sc.render(cam, rtx.options(batch_rays=16384, pool_rays=16384, **kw), out=out)
+    assert err.value.status == rtx.abi.RTX_ERR_QUEUE_OVERFLOW
+    again, ids2, st2 = sc.render(cam, rtx.options(**kw), out=out)
+    sc.close()
+    assert np.array_equal(ids, ids2) and st.rays_total == st2.rays_total
+    assert (np.abs(good.astype(int) - again.astype(int)) <= 1).all() and (good != again).mean() < 1e-3

@@ -99,10 +99,12 @@ def test_nearest_hits_on_degenerate_rays(rtx, orc, which):
     reference's own walk loses subtrees: BBox::intersects rejects a box whose near distance is a NaN (bbox.rs:124-164),
     and a ray within an ulp of a cell face can fail the f64 test of the cell that holds the prim it hits.
       * the all-f64 restatement (RTX_FLAG_REFERENCE_ORDER) reproduces the oracle bit for bit, prim and t;
-      * the renderer's conservative walk reaches a SUPERSET of the leaves and keeps the exact entry-bbox and prim tests, so
-        it returns the same hit or a nearer one that passes the reference's own prim test: never a farther one, never a
-        miss where the oracle hits; it differs only on rays with a direction component below 1e-12 (documented in
-        DESIGN.md; no camera or light of the BASELINE scenes produces such rays)."""
+      * the renderer's walk (k_closest + k_closest_retry) sends every ray with a direction component below 1e-9 through that
+        same all-f64 walk and everything else through the conservative near-to-far walk with the exact entry-bbox and prim
+        tests: t must equal the oracle's bit for bit on EVERY ray, and the prim may differ only where two prims hit at a
+        bit-identical t (the rays aim at cell corners, which in these scenes are mesh vertices and edges: the ordered walk
+        may meet the other prim of the tie first).  Each mismatch is verified as such a tie by
+        intersecting the GPU's prim alone in the oracle; the tie count is printed."""
     flat, cam_fn = _scene(rtx, which)
     rng = np.random.RandomState(23)
     n = 6000
@@ -122,11 +124,22 @@ def test_nearest_hits_on_degenerate_rays(rtx, orc, which):
     sc.close()
     assert (opid >= 0).sum() > 100
     assert np.array_equal(rpid, opid) and np.array_equal(rt.view(np.uint64), ot.view(np.uint64))
-    assert np.array_equal(tt.view(np.uint64), ot.view(np.uint64))   # degenerate rays take the all-f64 walk (k_closest_retry)
-    same_t = np.ones(len(tt), dtype=bool)
-    # exact ties in t between prims that share an edge or a vertex (these rays aim at cell corners, which in the cube scene
-    # are the cube's own vertices): the near-to-far walk may meet the other prim first
-    assert (pid[same_t] != opid[same_t]).mean() <= 0.05
+    assert np.array_equal(tt.view(np.uint64), ot.view(np.uint64))
+    kind, index = flat.prim_id_table()
+    ties = np.nonzero(pid != opid)[0]
+    for i in ties:
+        assert pid[i] >= 0 and opid[i] >= 0, "a miss on one side only (ray %d)" % i
+        k, j = kind[pid[i]], index[pid[i]]
+        if k == rtx.abi.PRIM_TRIANGLE:
+            h = orc.triangle_intersects(flat.tri_vertices[j], flat.tri_normals[j], flat.tri_uv[j], o[i], d[i], 1e-6, np.inf)
+        elif k == rtx.abi.PRIM_SPHERE:
+            h = orc.sphere_intersects(flat.sphere_center[j], float(flat.sphere_radius[j]), o[i], d[i], 1e-6, np.inf)
+        else:
+            h = orc.plane_intersects(flat.plane_abcd[j], o[i], d[i], 1e-6, np.inf)
+        assert h is not None and np.float64(h["t"]).view(np.uint64) == ot[i:i + 1].view(np.uint64)[0], \
+            "ray %d: prim %d is not an exact-t tie of the oracle's prim %d" % (i, pid[i], opid[i])
+    print("%s: %d exact-t ties among %d rays resolved to the other prim" % (which, len(ties), len(pid)))
+    assert len(ties) <= 0.05 * len(pid)   # adversarial set (rays through mesh vertices); camera rays: see the render parity tests
 
 
 @pytest.mark.parametrize("which", ["cornell", "mesh", "mesh_transmissive", "cube"])
@@ -396,7 +409,7 @@ def test_overlapped_shadow_launches_equal_serial_launches(rtx, which):
 
 @pytest.mark.parametrize("name,fov,opt", [
     ("bunny", 45.0, dict(reflect_depth=4, refract_depth=4, shadow_samples=1, pixel_samples=2)),
-    ("sponza", 67.5, dict(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=1)),
+    ("sponza", 67.5, dict(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=4)),   # config 3 as stated: 16 spp
     ("sibenik", 45.0, dict(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=1)),
 ])
 def test_baseline_scenes_full_size_properties(rtx, orc, name, fov, opt):

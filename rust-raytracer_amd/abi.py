@@ -122,7 +122,7 @@ class SceneInfo(C.Structure):
 # every symbol include/rtx.h declares
 EXPORTS = (
     "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_get_info", "rtx_render",
-    "rtx_render_device", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_octree_dump", "rtx_strerror",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_octree_dump", "rtx_strerror",
     "rtx_last_error", "rtx_version",
 )
 
@@ -153,6 +153,8 @@ def load():
     lib.rtx_render.restype = C.c_int32
     lib.rtx_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Options), vp, vp, vp, C.POINTER(Stats)]
     lib.rtx_render_device.restype = C.c_int32
+    lib.rtx_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Options), vp, vp, vp, C.POINTER(Stats)]
+    lib.rtx_render_device_noalloc.restype = C.c_int32
     lib.rtx_nearest_hits.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     lib.rtx_nearest_hits.restype = C.c_int32
     lib.rtx_nearest_hits_ex.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_uint32]

@@ -770,6 +770,12 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
     if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "device index out of range");
     HIPCHECK(hipSetDevice(device));
+    // set-up for rtx_render_device_noalloc: this device's address of the static scratch, resolved once with the device current
+    // (a failure is kept for that entry point to report; every other entry point works without the scratch)
+    {
+        int herr = 0;
+        (void)rtxk_static_scratch(device, &herr);
+    }
 
     const HostOctree &oct = fl.oct;
     int depth_for_stack = std::max(oct.depth, 0);
@@ -973,6 +979,11 @@ rtx_status rtx_scene_get_info(const rtx_scene *s, rtx_scene_info *info) {
 rtx_status rtx_render_device(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, void *rgba_out_dev,
                              void *primary_prim_id_out_dev, void *stream, rtx_stats *stats) {
     return render_impl(s, cam, opt, (uint8_t *)rgba_out_dev, (int32_t *)primary_prim_id_out_dev, (hipStream_t)stream, stats, false);
+}
+
+rtx_status rtx_render_device_noalloc(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, void *rgba_out_dev,
+                                     void *primary_prim_id_out_dev, void *stream, rtx_stats *stats) {
+    return render_impl(s, cam, opt, (uint8_t *)rgba_out_dev, (int32_t *)primary_prim_id_out_dev, (hipStream_t)stream, stats, true);
 }
 
 rtx_status rtx_render(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *rgba_out,

@@ -58,6 +58,15 @@ class Scene:
                                               C.byref(st) if want_stats else None), "rtx_render_device")
         return st
 
+    def render_device_noalloc(self, cam, opt, rgba_ptr, ids_ptr=None, stream=None, want_stats=True):
+        """rtx_render_device_noalloc: the same frame out of the library's static device scratch (allocates nothing)."""
+        st = abi.Stats() if want_stats else None
+        abi.check(self._lib.rtx_render_device_noalloc(self.h, C.byref(cam), C.byref(opt), C.c_void_p(rgba_ptr),
+                                                      C.c_void_p(ids_ptr) if ids_ptr else None,
+                                                      C.c_void_p(stream) if stream else None,
+                                                      C.byref(st) if want_stats else None), "rtx_render_device_noalloc")
+        return st
+
     def nearest_hits(self, origin, direction, flags=0):
         """rtx_nearest_hits_ex: flags 0 = the renderer's closest-hit walk, FLAG_REFERENCE_ORDER = the all-f64 walk."""
         o = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)

@@ -76,3 +76,40 @@ def gather_frames(frame, have_frame, rank, world, dist):
     if rank != 0:
         return None
     return [p if int(f.item()) else None for p, f in zip(parts, flags)]
+
+
+def animation_frames(fps, time_from, time_to):
+    """Animator::animate's frame list (animator.rs:24,45): total_frames = floor(fps * (to - from)), frame k at from + k / fps."""
+    total = int(fps * (time_to - time_from))
+    return [(k, time_from + k / fps) for k in range(total)]
+
+
+def frame_name(output_file, starting_frame_number, frame_number):
+    """animator.rs:35-37: `{output_file}{:06}.ppm`, numbered from starting_frame_number (restart of a partial animation)."""
+    return "%s%06d.ppm" % (output_file, starting_frame_number + frame_number)
+
+
+def animate(frames, rank, world, dist, render_frame, on_frame=None):
+    """N-rank animation driver: frame k of `frames` (a list of (frame_number, time)) is rendered by rank k % world with
+    render_frame(frame_number, time) -> [H, W, 4] uint8 tensor; after every round of `world` frames ONE gather brings the
+    round's frames to rank 0, which hands them to on_frame(frame_number, time, tensor) in frame order (the reference's
+    writer thread, animator.rs:27-42).  Returns the number of frames this rank rendered.  No other collective."""
+    rendered = 0
+    blank = None
+    for base in range(0, len(frames), world):
+        k = base + rank
+        have = k < len(frames)
+        if have:
+            frame = render_frame(*frames[k])
+            rendered += 1
+            blank = frame
+        else:
+            if blank is None:       # this rank has rendered nothing yet: it needs the frame's shape from a peer-independent source
+                raise RuntimeError("animate(): fewer frames than ranks; give every rank at least one frame")
+            frame = blank
+        parts = gather_frames(frame, have, rank, world, dist)
+        if rank == 0 and on_frame is not None:
+            for r, part in enumerate(parts):
+                if part is not None:
+                    on_frame(frames[base + r][0], frames[base + r][1], part)
+    return rendered

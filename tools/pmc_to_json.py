@@ -21,6 +21,7 @@ def load(db):
         if did not in seen:   # the profiler serialises the dispatches of a --pmc pass: this is the kernel alone
             seen.add(did)
             agg[k]["_seconds"] += (int(end) - int(start)) * 1e-9
+            agg[k]["_dispatches"] += 1
     return agg
 
 
@@ -41,7 +42,8 @@ def valu(k):
             "l2_hit_rate": 1.0 - w[k]["TCC_MISS_sum"] / w[k]["TCC_REQ_sum"],
             # L2 -> CU: 128-byte requests served by the L2 per second of the kernel running alone
             "l2_request_gbs": w[k]["TCC_REQ_sum"] * 128 / w[k]["_seconds"] / 1e9,
-            "hbm_gbs_alone": (f[k]["FETCH_SIZE"] * 2 + w[k]["WRITE_SIZE"]) * 1024 / w[k]["_seconds"] / 1e9}
+            "hbm_gbs_alone": (f[k]["FETCH_SIZE"] * 2 + w[k]["WRITE_SIZE"]) * 1024 / w[k]["_seconds"] / 1e9,
+            "alone_ms_per_launch": s[k]["_seconds"] * 1e3 / max(1.0, s[k]["_dispatches"])}
 
 
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")

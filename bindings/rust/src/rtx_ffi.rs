@@ -32,6 +32,13 @@ pub const RTX_RNG_PHILOX: u32 = 1;
 pub const RTX_FLAG_REFERENCE_ORDER: u32 = 1;
 pub const RTX_FLAG_NO_COOP: u32 = 2;
 pub const RTX_FLAG_SERIAL: u32 = 4;
+pub const RTX_PROBE_FRESNEL: i32 = 0;
+pub const RTX_PROBE_REFRACT: i32 = 1;
+pub const RTX_PROBE_REFLECT: i32 = 2;
+pub const RTX_PROBE_MATERIAL: i32 = 3;
+pub const RTX_PROBE_TEXTURE: i32 = 4;
+pub const RTX_PROBE_SKYBOX: i32 = 5;
+pub const RTX_PROBE_BBOX: i32 = 6;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -201,6 +208,7 @@ extern "C" {
                                shadow_out: *mut f64) -> RtxStatus;
     pub fn rtx_shadow_products_ex(scene: *mut RtxScene, n: i64, origin: *const f64, target: *const f64,
                                   shadow_out: *mut f64, flags: u32) -> RtxStatus;
+    pub fn rtx_shade_probe(scene: *mut RtxScene, which: i32, n: i64, input: *const f64, out: *mut f64) -> RtxStatus;
     pub fn rtx_octree_dump(desc: *const RtxSceneDesc, depth: *mut i32, n_nodes: *mut i64, n_entries: *mut i64,
                            bbox_out: *mut f64, shape_out: *mut i32, entries_out: *mut i32) -> RtxStatus;
     pub fn rtx_strerror(status: RtxStatus) -> *const c_char;

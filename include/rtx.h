@@ -303,6 +303,22 @@ rtx_status rtx_shadow_products(rtx_scene *scene, int64_t n, const double *origin
 rtx_status rtx_shadow_products_ex(rtx_scene *scene, int64_t n, const double *origin, const double *target,
                                   double *shadow_out, uint32_t flags);
 
+/* Parity probe for the shading functions the reference holds no test for: evaluates, on the device and with the very
+ * functions the shading kernel calls, one of
+ *   RTX_PROBE_FRESNEL   Renderer::fresnel_reflect (renderer.rs:226-247)     in: ior, i[3], n[3], inside          out: F
+ *   RTX_PROBE_REFRACT   Vec3::refract (vec3.rs:77-92)                       in: v[3], n[3], ior, inside          out: t[3], ok
+ *   RTX_PROBE_REFLECT   Vec3::reflect (vec3.rs:70-72)                       in: v[3], n[3]                       out: r[3]
+ *   RTX_PROBE_MATERIAL  Material::sample (cooktorrancematerial.rs:26-58, phongmaterial.rs:24-36, flatmaterial.rs:11-13)
+ *                                                                           in: material row, n[3], i[3], l[3], u, v   out: rgb
+ *   RTX_PROBE_TEXTURE   Texture::color (checkertexture.rs:13-23, uvtexture.rs:10-14, imagetexture.rs:26-47)
+ *                                                                           in: texture row, u, v                out: rgb
+ *   RTX_PROBE_SKYBOX    CubeMap::color (cubemap.rs:45-84)                   in: direction[3]                     out: rgb
+ *   RTX_PROBE_BBOX      BBox::intersects (bbox.rs:99-165)                   in: min[3], max[3], origin[3], direction[3]   out: 0 / 1
+ * for n argument rows: in[n][16] doubles (unused columns ignored, booleans as 0 / 1), out[n][4] doubles; host arrays. */
+enum { RTX_PROBE_FRESNEL = 0, RTX_PROBE_REFRACT = 1, RTX_PROBE_REFLECT = 2, RTX_PROBE_MATERIAL = 3, RTX_PROBE_TEXTURE = 4,
+       RTX_PROBE_SKYBOX = 5, RTX_PROBE_BBOX = 6 };
+rtx_status rtx_shade_probe(rtx_scene *scene, int32_t which, int64_t n, const double *in, double *out);
+
 /* Diagnostic, needs no device: the octree rtx_scene_create builds for `desc` (Octree::from_iter,
  * octree.rs:15-43), dumped in DFS pre-order with children 0..7: per node 6 doubles (bbox min,
  * max) and 2 ints (number of children: 0 or 8, number of leaf entries); entries_out receives

@@ -22,6 +22,7 @@ RNG_CENTER, RNG_PHILOX = 0, 1
 FLAG_REFERENCE_ORDER = 1
 FLAG_NO_COOP = 2
 FLAG_SERIAL = 4
+PROBE_FRESNEL, PROBE_REFRACT, PROBE_REFLECT, PROBE_MATERIAL, PROBE_TEXTURE, PROBE_SKYBOX, PROBE_BBOX = range(7)
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -122,7 +123,7 @@ class SceneInfo(C.Structure):
 # every symbol include/rtx.h declares
 EXPORTS = (
     "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_get_info", "rtx_render",
-    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_octree_dump", "rtx_strerror",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_shade_probe", "rtx_octree_dump", "rtx_strerror",
     "rtx_last_error", "rtx_version",
 )
 
@@ -163,6 +164,8 @@ def load():
     lib.rtx_shadow_products.restype = C.c_int32
     lib.rtx_shadow_products_ex.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_uint32]
     lib.rtx_shadow_products_ex.restype = C.c_int32
+    lib.rtx_shade_probe.argtypes = [vp, C.c_int32, C.c_int64, vp, vp]
+    lib.rtx_shade_probe.restype = C.c_int32
     lib.rtx_octree_dump.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), vp, vp, vp]
     lib.rtx_octree_dump.restype = C.c_int32

@@ -247,6 +247,7 @@ struct rtx_scene {
     rtx_scene_info info{};
     std::vector<rtx_light> lights;
     bool any_reflective = false, any_refractive = false, any_glossy = false;
+    int n_materials = 0, n_textures = 0;
     Work w;
 };
 
@@ -936,6 +937,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         (st = upload(s.get(), s->lights, &ds.lights)))
         return cleanup(st);
     if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane octree walk
+    s->n_materials = d->n_materials;
+    s->n_textures = d->n_textures;
     ds.n_planes = (int32_t)planes.size();
     ds.n_lights = d->n_lights;
     ds.has_skybox = d->skybox_image[0] >= 0 ? 1 : 0;
@@ -1069,6 +1072,33 @@ rtx_status rtx_shadow_products_ex(rtx_scene *s, int64_t n, const double *origin,
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return done(fail(RTX_ERR_HIP, "k_shadow_products failed"));
     if (hipMemcpy(shadow_out, d_out, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess)
         return done(fail(RTX_ERR_HIP, "download failed"));
+    return done(RTX_OK);
+}
+
+rtx_status rtx_shade_probe(rtx_scene *s, int32_t which, int64_t n, const double *in, double *out) {
+    if (!s || n < 0 || (n && (!in || !out))) return fail(RTX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (which < RTX_PROBE_FRESNEL || which > RTX_PROBE_BBOX) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown probe");
+    if (n == 0) return RTX_OK;
+    if (which == RTX_PROBE_SKYBOX && !s->d.has_skybox) return fail(RTX_ERR_INVALID_ARGUMENT, "the scene has no skybox");
+    for (int64_t i = 0; i < n; ++i) {   // table rows are indices: validate them here, the kernel does not
+        double row = in[i * 16];
+        if (which == RTX_PROBE_MATERIAL && !(row >= 0 && row < (double)s->n_materials && row == (double)(int)row))
+            return fail(RTX_ERR_INVALID_ARGUMENT, "material row out of range");
+        if (which == RTX_PROBE_TEXTURE && !(row >= 0 && row < (double)s->n_textures && row == (double)(int)row))
+            return fail(RTX_ERR_INVALID_ARGUMENT, "texture row out of range");
+    }
+    HIPCHECK(hipSetDevice(s->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    auto done = [&](rtx_status e) {
+        hipFree(d_in); hipFree(d_out);
+        return e;
+    };
+    rtx_status st;
+    if ((st = dev_alloc(&d_in, (size_t)n * 16)) || (st = dev_alloc(&d_out, (size_t)n * 4))) return done(st);
+    if (hipMemcpy(d_in, in, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(RTX_ERR_HIP, "upload failed"));
+    rtxk_shade_probe(nullptr, s->d, which, n, d_in, d_out);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return done(fail(RTX_ERR_HIP, "k_shade_probe failed"));
+    if (hipMemcpy(out, d_out, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return done(fail(RTX_ERR_HIP, "download failed"));
     return done(RTX_OK);
 }
 

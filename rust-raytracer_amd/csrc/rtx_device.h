@@ -200,6 +200,7 @@ void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double
                   int32_t *prim_id, double *t_out, uint32_t flags);
 void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
                           double *out, uint32_t flags);
+void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out);
 // sets counters->pool_tail, clears counters->overflow (a one-thread kernel: the allocation-free entry point has no pinned
 // host buffer to copy them from)
 void rtxk_set_pool_tail(rtx_stream_t stream, DCounters *counters, uint32_t pool_tail);

@@ -2140,6 +2140,48 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_
     out[gid * 3] = v.x; out[gid * 3 + 1] = v.y; out[gid * 3 + 2] = v.z;
 }
 
+// Probe behind rtx_shade_probe: the shading device functions of k_shade evaluated on caller-supplied arguments (the same functions,
+// not copies), so that per-function golden vectors can be compared without going through a whole frame and its 8-bit quantisation.
+__global__ void __launch_bounds__(RTX_BLOCK) k_shade_probe(DScene sc, int which, int64_t n, const double *in, double *out) {
+    int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (gid >= n) return;
+    const double *a = in + gid * 16;
+    double *o = out + gid * 4;
+    V3 r = v3(0, 0, 0);
+    double w = 0.0;
+    switch (which) {
+    case RTX_PROBE_FRESNEL:    // ior, i, n, inside                       (renderer.rs:226-247)
+        r.x = fresnel_reflect(a[0], v3(a[1], a[2], a[3]), v3(a[4], a[5], a[6]), a[7] != 0.0);
+        break;
+    case RTX_PROBE_REFRACT: {  // v, n, ior, inside -> direction, ok      (vec3.rs:77-92)
+        V3 t = v3(0, 0, 0);
+        w = refract(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6], a[7] != 0.0, &t) ? 1.0 : 0.0;
+        r = t;
+        break;
+    }
+    case RTX_PROBE_REFLECT:    // v, n                                    (vec3.rs:70-72)
+        r = reflect(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]));
+        break;
+    case RTX_PROBE_MATERIAL:   // material row, n, i, l, u, v             (Material::sample of the row's kind)
+        r = material_sample(sc, sc.materials[(int)a[0]], v3(a[1], a[2], a[3]), v3(a[4], a[5], a[6]), v3(a[7], a[8], a[9]), a[10], a[11]);
+        break;
+    case RTX_PROBE_TEXTURE:    // texture row, u, v                       (Texture::color of the row's kind)
+        r = texture_color(sc, (int)a[0], a[1], a[2]);
+        break;
+    case RTX_PROBE_SKYBOX:     // direction                               (cubemap.rs:45-84)
+        r = cubemap_color(sc, v3(a[0], a[1], a[2]));
+        break;
+    case RTX_PROBE_BBOX: {     // bbox min, max, ray origin, direction -> intersects (bbox.rs:99-165)
+        double tn, tf;
+        r.x = slab(a[0], a[1], a[2], a[3], a[4], a[5], make_ray(v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11])), &tn, &tf) ? 1.0 : 0.0;
+        break;
+    }
+    default:
+        break;
+    }
+    o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = w;
+}
+
 // ================================================================================ launch wrappers
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + RTX_BLOCK - 1) / RTX_BLOCK); }
 
@@ -2206,6 +2248,10 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
 __global__ void k_set_pool_tail(DCounters *counters, uint32_t pool_tail) {
     counters->pool_tail = pool_tail;
     counters->overflow = 0u;
+}
+void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_shade_probe, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, which, n, in, out);
 }
 __global__ void k_init_counters(DCounters *counters, unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS]) {
     DCounters c = {};

@@ -79,6 +79,16 @@ class Scene:
                   "rtx_nearest_hits_ex")
         return pid, t
 
+    def shade_probe(self, which, rows):
+        """rtx_shade_probe: `rows` is a list of argument rows (<= 16 numbers each); returns out[n, 4]."""
+        a = np.zeros((len(rows), 16), dtype=np.float64)
+        for i, r in enumerate(rows):
+            a[i, :len(r)] = r
+        out = np.zeros((len(rows), 4), dtype=np.float64)
+        abi.check(self._lib.rtx_shade_probe(self.h, which, len(rows), a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
+                  "rtx_shade_probe")
+        return out
+
     def shadow_products(self, origin, target, flags=0):
         """rtx_shadow_products_ex: flags 0 = the renderer's product walk, FLAG_REFERENCE_ORDER = the all-f64 walk."""
         o = np.ascontiguousarray(origin, dtype=np.float64).reshape(-1, 3)

@@ -1474,6 +1474,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_retry(DScene sc, DFrame fr
 #define RTX_COOP_WAVES_MULTI 5   // several hit points per group: 16 spills at 6 (sibenik frame 12.7 -> 14.0 ms)
 #endif
 #define RTX_COOP_PAIRS 128    // 63 waiting + 64 pushed in one step at most
+#ifndef RTX_COOP_DEFER_ENTRY
+#define RTX_COOP_DEFER_ENTRY 1   // the f64 entry-bbox test of a shadow candidate runs once per stopped feeler, after the walk (see run_pairs)
+#endif
 static_assert(RTX_COOP_QT - 1 + 32 <= RTX_COOP_QUEUE, "primitive queue too small for the drain threshold");
 // a waiting pair in one word: prim kind (2 bits) | owner lane and surely_in (7 bits) | prim index (23 bits: the host keeps scenes with
 // 2^23 triangles or spheres or more off this kernel)
@@ -1803,6 +1806,34 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
             const bool surely_in = (pr.y & 64u) != 0u;
             const uint32_t idx = pr.x & RTX_WREF_INDEX;
             bool occluded = false;
+#if RTX_COOP_DEFER_ENTRY
+            // DEFERRED ENTRY-BBOX TEST.  A candidate counts iff its own bbox passes (octree.rs:170) AND the primitive test passes
+            // (renderer.rs:212): two pure predicates, so their order is free.  Every pair here has passed the widened f32 box
+            // test, which the f64 test fails only within delta of the box: run in place it costs as much as the primitive test
+            // (three divisions for the inverse direction, min/max of the vertices, the slab test) and practically never
+            // rejects.  So the primitive test runs alone; a hit whose box was not "surely in" is TENTATIVE: it stops the
+            // feeler like a hit and records its primitive, and the feeler's own lane runs the f64 bbox test once, after the
+            // walk (confirm pass below).  A hit that fails it (seen only in the forced-failure test build) does not count, and
+            // the feeler is answered by the all-f64 walk through the launch's retry list, like a degenerate one.
+            (void)entry_ray;
+            uint32_t kind_bit = 0u;
+            if ((pr.x & RTX_WREF_KIND) == RTX_WREF_TRI) {
+                int pid, mat;
+                TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
+                WORK(++w_prims;)
+                double t, be, ga;
+                occluded = tri_hit(tr, q, EPSILON, q_dist, &t, &be, &ga);
+            } else {
+                const DSphere &sp_ = sc.spheres[idx];
+                WORK(++w_prims;)
+                double t;
+                occluded = sphere_hit(v3(sp_.c[0], sp_.c[1], sp_.c[2]), sp_.r, q, EPSILON, q_dist, &t);
+                kind_bit = 8u;
+            }
+            // bit 0: confirmed occluder; bit 2: tentative, bit 3: sphere, bits 4..: primitive index (< 2^23).  Several pairs
+            // of one feeler may write in the same round: any of them will do (a failed confirmation goes to the exact walk)
+            if (occluded) s_hit[owner] = surely_in ? 1u : (4u | kind_bit | (idx << 4));
+#else
             if ((pr.x & RTX_WREF_KIND) == RTX_WREF_TRI) {
                 int pid, mat;
                 TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
@@ -1821,9 +1852,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
                 }
             }
             if (occluded) s_hit[owner] = 1u;
+#endif
         }
         COOP_FENCE();
-        if (s_hit[threadIdx.x] & 1u) { alive = false; seek = false; }
+        if (s_hit[threadIdx.x] & 5u) { alive = false; seek = false; }
     };
 
     for (;;) {
@@ -2006,6 +2038,34 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     }
 
     while (pair_n > 0u) run_pairs();   // what the last drains left waiting (RTX_COOP_PT > 1 only)
+#if RTX_COOP_DEFER_ENTRY
+    {   // confirm pass: every feeler stopped by a tentative hit runs the f64 entry-bbox test of that primitive, once, on its own lane
+        COOP_FENCE();
+        const uint32_t hw = s_hit[threadIdx.x];
+        if (hw & 4u) {
+            const uint32_t oi = MULTI ? threadIdx.x : sub;
+            const Ray e = make_ray(v3(s_org[0][oi], s_org[1][oi], s_org[2][oi]),
+                                   v3(s_ray[0][threadIdx.x], s_ray[1][threadIdx.x], s_ray[2][threadIdx.x]));   // ray.rs:23-42
+            const uint32_t idx = hw >> 4;
+            bool ok;
+            if (hw & 8u) {
+                const DSphere &sp_ = sc.spheres[idx];
+                ok = sphere_bbox_hit(v3(sp_.c[0], sp_.c[1], sp_.c[2]), sp_.r, e);
+            } else {
+                int pid, mat;
+                const TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
+                ok = tri_bbox_hit(tr, e);
+            }
+#ifdef RTX_DEBUG_FAIL_CONFIRM
+            if ((idx + threadIdx.x) % RTX_DEBUG_FAIL_CONFIRM == 0u) ok = false;   // test build: exercise the hand-off below
+#endif
+            if (!ok) {   // the recorded hit does not count: the feeler stays out of this kernel's sum and takes the all-f64 walk
+                const uint64_t g_ = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+                retry_append(sq, light, (uint32_t)g_, sq.sample[(size_t)light * qc + (uint32_t)(g_ / tries)], counters);
+            }
+        }
+    }
+#endif
     // infinite prims (planes), octree.rs:163-165: a feeler that is still clear tests them in order
     if (alive && !wide) {
         Ray q;      // the lane's own feeler again (kept in LDS, not in registers, during the walk)

@@ -6,9 +6,16 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <functional>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -41,66 +48,42 @@ rtx_status fail(rtx_status st, const std::string &msg) {
 struct HBox {
     double mn[3], mx[3];
 };
-struct HNode {
-    HBox bbox;
-    int depth;
-    int first_child = -1;
-    std::vector<int> entries;   // leaf_data indices; the entry's bbox is the prim's own bbox
-};
 bool overlaps(const HBox &a, const HBox &o) {                      // geometry/bbox.rs:167-173
     bool x = a.mx[0] >= o.mn[0] && a.mn[0] <= o.mx[0];
     bool y = a.mx[1] >= o.mn[1] && a.mn[1] <= o.mx[1];
     bool z = a.mx[2] >= o.mn[2] && a.mn[2] <= o.mx[2];
     return x && y && z;
 }
+// One node of the finished octree: leaf entries are a range of HostOctree::entries (prim indices, insertion order).
+struct FNode {
+    HBox bbox;
+    int depth;
+    int first_child = -1;     // its 8 children are contiguous (octree.rs:75-98), -1: leaf
+    int ebegin = 0, ecount = 0;
+};
 struct HostOctree {
-    std::vector<HNode> nodes;
+    std::vector<FNode> nodes;     // children always have larger indices than their parent
+    std::vector<int> entries;
     std::vector<HBox> prim_box;   // finite prims, insertion order
     int depth = 0;
 
-    void subdivide(int ni) {                                       // octree.rs:75-98
-        int first = (int)nodes.size();
-        HBox b = nodes[ni].bbox;
-        int d = nodes[ni].depth;
+    static void child_boxes(const HBox &b, HBox out[8]) {          // octree.rs:75-98, child k = x*4 + y*2 + z
+        int k = 0;
         for (unsigned x = 0; x < 2; ++x)
             for (unsigned y = 0; y < 2; ++y)
-                for (unsigned z = 0; z < 2; ++z) {
+                for (unsigned z = 0; z < 2; ++z, ++k) {
                     double lx = b.mx[0] - b.mn[0], ly = b.mx[1] - b.mn[1], lz = b.mx[2] - b.mn[2];
-                    HNode ch;
-                    ch.bbox.mn[0] = b.mn[0] + (double)x * lx / 2.0;
-                    ch.bbox.mn[1] = b.mn[1] + (double)y * ly / 2.0;
-                    ch.bbox.mn[2] = b.mn[2] + (double)z * lz / 2.0;
-                    ch.bbox.mx[0] = b.mx[0] - (double)(1 - x) * lx / 2.0;
-                    ch.bbox.mx[1] = b.mx[1] - (double)(1 - y) * ly / 2.0;
-                    ch.bbox.mx[2] = b.mx[2] - (double)(1 - z) * lz / 2.0;
-                    ch.depth = d - 1;
-                    nodes.push_back(std::move(ch));
+                    out[k].mn[0] = b.mn[0] + (double)x * lx / 2.0;
+                    out[k].mn[1] = b.mn[1] + (double)y * ly / 2.0;
+                    out[k].mn[2] = b.mn[2] + (double)z * lz / 2.0;
+                    out[k].mx[0] = b.mx[0] - (double)(1 - x) * lx / 2.0;
+                    out[k].mx[1] = b.mx[1] - (double)(1 - y) * ly / 2.0;
+                    out[k].mx[2] = b.mx[2] - (double)(1 - z) * lz / 2.0;
                 }
-        nodes[ni].first_child = first;
     }
-    void insert(int ni, int index) {                               // octree.rs:101-128
-        if (nodes[ni].depth <= 0) {
-            nodes[ni].entries.push_back(index);
-            return;
-        }
-        bool leaf = nodes[ni].first_child < 0;
-        if (leaf && nodes[ni].entries.empty()) {
-            nodes[ni].entries.push_back(index);
-            return;
-        }
-        if (leaf && nodes[ni].entries.size() == 1) {
-            subdivide(ni);
-            int old = nodes[ni].entries[0];
-            nodes[ni].entries.clear();
-            insert(ni, old);
-        }
-        int first = nodes[ni].first_child;
-        for (int c = 0; c < 8; ++c)
-            if (overlaps(nodes[first + c].bbox, prim_box[index])) insert(first + c, index);
-    }
-    void build() {                                                 // octree.rs:15-43
-        HBox bounds{{0, 0, 0}, {0, 0, 0}};                         // BBox::zero() when empty
-        for (size_t i = 0; i < prim_box.size(); ++i) {             // BBox::from_union, bbox.rs:85-97
+    HBox root_bounds() const {                                     // BBox::from_union, bbox.rs:85-97 (BBox::zero() when empty)
+        HBox bounds{{0, 0, 0}, {0, 0, 0}};
+        for (size_t i = 0; i < prim_box.size(); ++i) {
             const HBox &p = prim_box[i];
             if (i == 0) bounds = p;
             else
@@ -109,25 +92,211 @@ struct HostOctree {
                     bounds.mx[a] = std::fmax(bounds.mx[a], p.mx[a]);
                 }
         }
+        return bounds;
+    }
+    int root_depth() const {                                       // octree.rs:29
         double dd = std::round(1.2 * (std::log((double)prim_box.size()) / std::log(8.0)));
         // `as i32` saturates (N = 0 gives -inf -> i32::MIN: the root stays a leaf)
-        depth = dd != dd ? 0 : (dd <= -2147483648.0 ? INT32_MIN : (dd >= 2147483647.0 ? INT32_MAX : (int)dd));
-        HNode root;
-        root.bbox = bounds;
-        root.depth = depth;
-        nodes.clear();
-        nodes.push_back(std::move(root));
-        for (size_t i = 0; i < prim_box.size(); ++i) insert(0, (int)i);
+        return dd != dd ? 0 : (dd <= -2147483648.0 ? INT32_MIN : (dd >= 2147483647.0 ? INT32_MAX : (int)dd));
     }
-    bool nonempty(int ni, std::vector<int8_t> &memo) const {
-        if (memo[ni] >= 0) return memo[ni] != 0;
-        bool ne = !nodes[ni].entries.empty();
-        if (nodes[ni].first_child >= 0)
-            for (int c = 0; c < 8; ++c) ne = nonempty(nodes[ni].first_child + c, memo) || ne;
-        memo[ni] = ne ? 1 : 0;
-        return ne;
+
+    // ---- Octree::from_iter + OctreeNode::{subdivide, insert} (raytracer/octree.rs:15-43, 64-133), statement for statement, with
+    // index-linked nodes instead of nested Vecs.  Kept as the cross-check of the parallel build below (RTX_BUILD_THREADS=0).
+    struct SNode {
+        HBox bbox;
+        int depth;
+        int first_child = -1;
+        std::vector<int> entries;
+    };
+    void seq_subdivide(std::vector<SNode> &sn, int ni) const {     // octree.rs:75-98
+        int first = (int)sn.size();
+        HBox cb[8];
+        child_boxes(sn[(size_t)ni].bbox, cb);
+        int d = sn[(size_t)ni].depth;
+        for (int c = 0; c < 8; ++c) {
+            SNode ch;
+            ch.bbox = cb[c];
+            ch.depth = d - 1;
+            sn.push_back(std::move(ch));
+        }
+        sn[(size_t)ni].first_child = first;
+    }
+    void seq_insert(std::vector<SNode> &sn, int ni, int index) const {   // octree.rs:101-128
+        if (sn[(size_t)ni].depth <= 0) {
+            sn[(size_t)ni].entries.push_back(index);
+            return;
+        }
+        bool leaf = sn[(size_t)ni].first_child < 0;
+        if (leaf && sn[(size_t)ni].entries.empty()) {
+            sn[(size_t)ni].entries.push_back(index);
+            return;
+        }
+        if (leaf && sn[(size_t)ni].entries.size() == 1) {
+            seq_subdivide(sn, ni);
+            int old = sn[(size_t)ni].entries[0];
+            sn[(size_t)ni].entries.clear();
+            seq_insert(sn, ni, old);
+        }
+        int first = sn[(size_t)ni].first_child;
+        for (int c = 0; c < 8; ++c)
+            if (overlaps(sn[(size_t)(first + c)].bbox, prim_box[(size_t)index])) seq_insert(sn, first + c, index);
+    }
+    void build() {                                                 // octree.rs:15-43
+        depth = root_depth();
+        std::vector<SNode> sn;
+        SNode root;
+        root.bbox = root_bounds();
+        root.depth = depth;
+        sn.push_back(std::move(root));
+        for (size_t i = 0; i < prim_box.size(); ++i) seq_insert(sn, 0, (int)i);
+        nodes.resize(sn.size());
+        entries.clear();
+        for (size_t i = 0; i < sn.size(); ++i) {
+            FNode &f = nodes[i];
+            f.bbox = sn[i].bbox; f.depth = sn[i].depth; f.first_child = sn[i].first_child;
+            f.ebegin = (int)entries.size(); f.ecount = (int)sn[i].entries.size();
+            entries.insert(entries.end(), sn[i].entries.begin(), sn[i].entries.end());
+        }
+    }
+
+    // ---- the same tree, built top-down and in parallel -------------------------------------------------------------------
+    // What insert() does to a node depends only on the node's depth and on the ORDERED list of prims that reach it: a node of
+    // depth <= 0 keeps them all (octree.rs:103-106); with depth > 0 it keeps a lone prim (:109-112) and, from the second prim on,
+    // is an interior node that has handed every prim, the first one included (:114-120), in order, to each child whose bbox
+    // overlaps the prim's (:122-127).  So the subtree of a node is a function of (bbox, depth, ordered prim list): interior iff
+    // depth > 0 and the list has two or more prims; child c's list = the prims of the list that overlap c's bbox, in order.
+    // Sibling subtrees are independent, which the sequential insertion hides: the top two levels are expanded here and the
+    // subtrees below them are built by worker threads into local arrays that are appended afterwards (node numbering differs from
+    // the sequential build's, the tree does not: rtx_octree_dump / test_octree_matches_oracle_bit_for_bit compare it with the
+    // oracle's sequentially inserted one).  Child boxes come from subdivide()'s expressions.
+    struct Local {
+        std::vector<FNode> nodes;   // [0] = the subtree's root
+        std::vector<int> entries;
+    };
+    // builds the subtree of L.nodes[0] (bbox and depth set) from its ordered prim list
+    void build_subtree(Local &L, std::vector<int> list) const {
+        struct Item { int node; std::vector<int> list; };
+        std::vector<Item> stack;
+        stack.push_back(Item{0, std::move(list)});
+        while (!stack.empty()) {
+            Item it = std::move(stack.back());
+            stack.pop_back();
+            if (L.nodes[(size_t)it.node].depth <= 0 || it.list.size() < 2) {
+                L.nodes[(size_t)it.node].ebegin = (int)L.entries.size();
+                L.nodes[(size_t)it.node].ecount = (int)it.list.size();
+                L.entries.insert(L.entries.end(), it.list.begin(), it.list.end());
+                continue;
+            }
+            HBox cb[8];
+            child_boxes(L.nodes[(size_t)it.node].bbox, cb);
+            const int first = (int)L.nodes.size(), d = L.nodes[(size_t)it.node].depth;
+            L.nodes[(size_t)it.node].first_child = first;
+            for (int c = 0; c < 8; ++c) {
+                FNode ch;
+                ch.bbox = cb[c];
+                ch.depth = d - 1;
+                L.nodes.push_back(ch);
+            }
+            for (int c = 0; c < 8; ++c) {
+                std::vector<int> sub;
+                for (int i : it.list)
+                    if (overlaps(cb[c], prim_box[(size_t)i])) sub.push_back(i);
+                stack.push_back(Item{first + c, std::move(sub)});
+            }
+        }
+    }
+    void build_parallel(RtxPool &pool) {
+        depth = root_depth();
+        nodes.clear();
+        entries.clear();
+        FNode root;
+        root.bbox = root_bounds();
+        root.depth = depth;
+        nodes.push_back(root);
+        std::vector<int> all(prim_box.size());
+        for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
+        auto make_leaf = [&](int ni, const std::vector<int> &list) {
+            nodes[(size_t)ni].ebegin = (int)entries.size();
+            nodes[(size_t)ni].ecount = (int)list.size();
+            entries.insert(entries.end(), list.begin(), list.end());
+        };
+        if (depth <= 0 || all.size() < 2) {
+            make_leaf(0, all);
+            return;
+        }
+        // level 1: the root's eight children and their lists
+        HBox cb[8];
+        child_boxes(nodes[0].bbox, cb);
+        nodes[0].first_child = 1;
+        for (int c = 0; c < 8; ++c) {
+            FNode ch;
+            ch.bbox = cb[c];
+            ch.depth = depth - 1;
+            nodes.push_back(ch);
+        }
+        std::vector<std::vector<int>> lists(8);
+        pool.run(8, [&](size_t c) {
+            for (int i : all)
+                if (overlaps(cb[c], prim_box[(size_t)i])) lists[c].push_back(i);
+        });
+        // level 2 where a child is interior: its eight children are the roots of the subtrees the workers build
+        struct Sub { int node; int parent_list; };
+        std::vector<Sub> subs;
+        for (int c = 0; c < 8; ++c) {
+            if (nodes[(size_t)(1 + c)].depth <= 0 || lists[(size_t)c].size() < 2) {
+                make_leaf(1 + c, lists[(size_t)c]);
+                continue;
+            }
+            HBox gb[8];
+            child_boxes(nodes[(size_t)(1 + c)].bbox, gb);
+            const int first = (int)nodes.size(), d = nodes[(size_t)(1 + c)].depth;
+            nodes[(size_t)(1 + c)].first_child = first;
+            for (int g = 0; g < 8; ++g) {
+                FNode gn;
+                gn.bbox = gb[g];
+                gn.depth = d - 1;
+                nodes.push_back(gn);
+                subs.push_back(Sub{first + g, c});
+            }
+        }
+        std::vector<Local> local(subs.size());
+        pool.run(subs.size(), [&](size_t t) {
+            const Sub &sb = subs[t];
+            std::vector<int> list;
+            for (int i : lists[(size_t)sb.parent_list])
+                if (overlaps(nodes[(size_t)sb.node].bbox, prim_box[(size_t)i])) list.push_back(i);
+            local[t].nodes.push_back(nodes[(size_t)sb.node]);
+            build_subtree(local[t], std::move(list));
+        });
+        // append: local node j > 0 of subtree t becomes node_base[t] + j - 1, local node 0 is nodes[subs[t].node]; offsets first, copies in parallel
+        std::vector<size_t> node_base(subs.size()), entry_base(subs.size());
+        size_t nn = nodes.size(), ne = entries.size();
+        for (size_t t = 0; t < subs.size(); ++t) {
+            node_base[t] = nn; entry_base[t] = ne;
+            nn += local[t].nodes.size() - 1; ne += local[t].entries.size();
+        }
+        nodes.resize(nn);
+        entries.resize(ne);
+        pool.run(subs.size(), [&](size_t t) {
+            Local &L = local[t];
+            const int shift = (int)node_base[t] - 1;
+            for (size_t j = 0; j < L.nodes.size(); ++j) {
+                FNode f = L.nodes[j];
+                if (f.first_child >= 0) f.first_child += shift;
+                f.ebegin += (int)entry_base[t];
+                nodes[j == 0 ? (size_t)subs[t].node : node_base[t] + j - 1] = f;
+            }
+            std::copy(L.entries.begin(), L.entries.end(), entries.begin() + (long)entry_base[t]);
+        });
     }
 };
+
+// worker threads of the host-side builds (octree subtrees, SAH box lists): the process's share of the box, 16 at most
+unsigned build_threads() {
+    if (const char *e = std::getenv("RTX_BUILD_THREADS")) return (unsigned)std::max(0, std::atoi(e));
+    unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hc ? hc : 1u));
+}
 
 // Flattened, validated view of an rtx_scene_desc with prims split by finiteness.
 struct Flat {
@@ -136,6 +305,13 @@ struct Flat {
     HostOctree oct;
 };
 
+void build_octree(Flat &fl, RtxPool *pool) {
+    // pool == NULL (RTX_BUILD_THREADS=0): the sequential insertion of octree.rs, statement for statement (same tree; the cross-check)
+    if (!pool) fl.oct.build();
+    else fl.oct.build_parallel(*pool);
+}
+
+// validation + the prims split by finiteness, with their boxes; the octree is built by build_octree()
 rtx_status flatten(const rtx_scene_desc *d, Flat &fl) {
     if (!d) return fail(RTX_ERR_INVALID_ARGUMENT, "desc is NULL");
     if (d->n_spheres < 0 || d->n_planes < 0 || d->n_triangles < 0 || d->n_materials < 0 || d->n_textures < 0 ||
@@ -202,7 +378,6 @@ rtx_status flatten(const rtx_scene_desc *d, Flat &fl) {
         fl.fin_index.push_back(idx);
         fl.oct.prim_box.push_back(b);
     }
-    fl.oct.build();
     return RTX_OK;
 }
 
@@ -253,18 +428,99 @@ struct rtx_scene {
 
 namespace {
 
-template <class T>
-rtx_status upload(rtx_scene *s, const std::vector<T> &v, const T **out) {
-    T *p = nullptr;
-    size_t n = std::max<size_t>(v.size(), 1);
-    HIPCHECK(hipMalloc((void **)&p, n * sizeof(T)));
-    s->allocs.push_back(p);
-    HIPCHECK(hipMemset(p, 0, n * sizeof(T)));
-    if (!v.empty()) HIPCHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    s->info.device_bytes += (int64_t)(n * sizeof(T));
-    *out = p;
-    return RTX_OK;
-}
+// Uploads on a thread of their own, so that the first host-to-device copies of a process (which pay the runtime's one-off set-up:
+// measured 150 ms for the first 100 MB, 8 ms for the same bytes in a second scene) and the copies themselves run beside the host-side
+// builds instead of after them.  submit() queues one array (the source must stay alive until finish()); *out is valid after finish().
+class Uploader {
+public:
+    explicit Uploader(int device) : device_(device), th_([this]() { loop(); }) {}
+    ~Uploader() { (void)finish(nullptr); }
+    template <class T>
+    void submit(const T *src, size_t n, const T **out) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(Job{src, n * sizeof(T), (const void **)out});
+        }
+        cv_.notify_one();
+    }
+    template <class T>
+    void submit(const std::vector<T> &v, const T **out) { submit(v.data(), v.size(), out); }
+    // waits for the queue to drain; hands the device allocations to the scene (also on failure, so that the caller's cleanup frees them)
+    rtx_status finish(rtx_scene *s) {
+        if (th_.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                closing_ = true;
+            }
+            cv_.notify_one();
+            th_.join();
+        }
+        if (s) {
+            for (void *p : allocs_) s->allocs.push_back(p);
+            allocs_.clear();
+            s->info.device_bytes += bytes_;
+            bytes_ = 0;
+        } else {
+            for (void *p : allocs_) hipFree(p);
+            allocs_.clear();
+        }
+        if (st_ != RTX_OK) return fail(st_, err_);
+        return RTX_OK;
+    }
+
+private:
+    struct Job { const void *src; size_t bytes; const void **out; };
+    void loop() {
+        hipError_t e = hipSetDevice(device_);
+        if (e == hipSuccess) {   // a process's first host-to-device copy pays ~140 ms of runtime set-up whatever its size (tools/exp/h2d_cold.cpp):
+            void *w = nullptr;   // pay it here, at once, beside the host-side builds
+            char z[64] = {0};
+            if (hipMalloc(&w, sizeof(z)) == hipSuccess) {
+                (void)hipMemcpy(w, z, sizeof(z), hipMemcpyHostToDevice);
+                (void)hipFree(w);
+            }
+            // set-up for rtx_render_device_noalloc: this device's address of the static scratch, resolved once with the device
+            // current (it loads the code object; a failure is kept for that entry point to report, nothing else needs the scratch)
+            int herr = 0;
+            (void)rtxk_static_scratch(device_, &herr);
+        }
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return closing_ || !q_.empty(); });
+                if (q_.empty()) return;
+                j = q_.front();
+                q_.pop_front();
+            }
+            if (st_ != RTX_OK) continue;   // after a failure the remaining jobs are dropped
+            void *p = nullptr;
+            const size_t bytes = std::max<size_t>(j.bytes, 1);
+            if (e == hipSuccess) e = hipMalloc(&p, bytes);
+            if (e == hipSuccess) {
+                allocs_.push_back(p);
+                bytes_ += (int64_t)bytes;
+                e = j.bytes ? hipMemcpy(p, j.src, j.bytes, hipMemcpyHostToDevice) : hipMemset(p, 0, bytes);
+            }
+            if (e != hipSuccess) {
+                st_ = e == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP;
+                err_ = std::string("scene upload: ") + hipGetErrorString(e);
+                continue;
+            }
+            *j.out = p;
+        }
+    }
+    int device_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job> q_;
+    bool closing_ = false;
+    rtx_status st_ = RTX_OK;
+    std::string err_;
+    std::vector<void *> allocs_;
+    int64_t bytes_ = 0;
+    std::thread th_;   // last: started when everything above exists
+};
 
 void free_work(Work &w) {
     if (w.pool.f) hipFree(w.pool.f);
@@ -763,6 +1019,14 @@ extern "C" {
 rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene **out) {
     if (!out) return fail(RTX_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
+    const bool timing = std::getenv("RTX_BUILD_TIMING") != nullptr;   // stage times of the build on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "rtx_scene_create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     Flat fl;
     rtx_status st = flatten(d, fl);
     if (st) return st;
@@ -771,13 +1035,12 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
     if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "device index out of range");
     HIPCHECK(hipSetDevice(device));
-    // set-up for rtx_render_device_noalloc: this device's address of the static scratch, resolved once with the device current
-    // (a failure is kept for that entry point to report; every other entry point works without the scratch)
-    {
-        int herr = 0;
-        (void)rtxk_static_scratch(device, &herr);
-    }
-
+    Uploader up(device);   // its thread warms the copy path up while the octree is built
+    lap("validate + device");
+    const unsigned n_threads_env = build_threads();
+    RtxPool pool(std::max(1u, n_threads_env));
+    build_octree(fl, n_threads_env ? &pool : nullptr);
+    lap("octree");
     const HostOctree &oct = fl.oct;
     int depth_for_stack = std::max(oct.depth, 0);
     if (depth_for_stack > RTX_MAX_LEVELS) return fail(RTX_ERR_LIMIT, "octree deeper than 12 levels");
@@ -792,12 +1055,15 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
 
     // prim records; prim id = rank among finite prims, planes after (rtx.h)
     int n_fin = (int)fl.fin_kind.size();
-    std::vector<DTri> tris((size_t)d->n_triangles);
-    std::vector<DTriShade> shade((size_t)d->n_triangles);
-    std::vector<DSphere> spheres((size_t)d->n_spheres);
+    // (new T[n] leaves plain records uninitialised: their pages are first touched by the parallel fill, not by a serial zero-fill)
+    const size_t n_tri = (size_t)d->n_triangles, n_sph = (size_t)d->n_spheres;
+    std::unique_ptr<DTri[]> tris(new DTri[std::max<size_t>(n_tri, 1)]);
+    std::unique_ptr<DTriShade[]> shade(new DTriShade[std::max<size_t>(n_tri, 1)]);
+    std::unique_ptr<DSphere[]> spheres(new DSphere[std::max<size_t>(n_sph, 1)]);
     std::vector<DPlane> planes(fl.inf_index.size());
     std::vector<int32_t> ref_of_prim((size_t)n_fin);
-    for (int i = 0; i < n_fin; ++i) {
+    pool.run(((size_t)n_fin + 16383) / 16384, [&](size_t chunk) {
+      for (int i = (int)(chunk * 16384); i < std::min(n_fin, (int)((chunk + 1) * 16384)); ++i) {
         int idx = fl.fin_index[(size_t)i];
         if (fl.fin_kind[(size_t)i] == RTX_PRIM_TRIANGLE) {
             DTri &t = tris[(size_t)idx];
@@ -818,7 +1084,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
             sp.pad = 0.0;
             ref_of_prim[(size_t)i] = ~idx;
         }
-    }
+      }
+    });
     for (size_t j = 0; j < fl.inf_index.size(); ++j) {
         int idx = fl.inf_index[j];
         DPlane &pl = planes[j];
@@ -827,83 +1094,7 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         pl.material = d->plane_material[idx];
         pl.pad = 0.0;
     }
-    // nodes + leaf entries
-    std::vector<DNode> nodes(oct.nodes.size());
-    std::vector<int32_t> leaf_refs;
-    std::vector<int8_t> memo(oct.nodes.size(), -1);
-    int n_interior = 0, max_entries = 0;
-    for (size_t i = 0; i < oct.nodes.size(); ++i) {
-        const HNode &hn = oct.nodes[i];
-        DNode &dn = nodes[i];
-        for (int a = 0; a < 3; ++a) { dn.bmin[a] = hn.bbox.mn[a]; dn.bmax[a] = hn.bbox.mx[a]; }
-        dn.first_child = hn.first_child;
-        dn.entry_begin = (int32_t)leaf_refs.size();
-        dn.entry_count = (int32_t)hn.entries.size();
-        dn.child_mask = 0;
-        if (hn.first_child >= 0) {
-            ++n_interior;
-            for (int c = 0; c < 8; ++c)
-                if (oct.nonempty(hn.first_child + c, memo)) dn.child_mask |= 1u << c;
-        }
-        for (int e : hn.entries) leaf_refs.push_back(ref_of_prim[(size_t)e]);
-        max_entries = std::max(max_entries, (int)hn.entries.size());
-    }
-    // conservative f32 twins (DNode32 / DEntry32): relative to the root centre, rounded outward
-    auto f32_down = [](double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; };
-    auto f32_up = [](double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; };
-    double centre[3], radius = 0.0;
-    for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (oct.nodes[0].bbox.mn[a] + oct.nodes[0].bbox.mx[a]);
-    auto widen_radius = [&](const HBox &b) {
-        for (int a = 0; a < 3; ++a) {
-            double lo = std::fabs(b.mn[a] - centre[a]), hi = std::fabs(b.mx[a] - centre[a]);
-            if (lo > radius) radius = lo;
-            if (hi > radius) radius = hi;
-        }
-    };
-    std::vector<DNode32> nodes32(oct.nodes.size());
-    std::vector<DEntry32> entries32;
-    entries32.reserve(leaf_refs.size());
-    for (size_t i = 0; i < oct.nodes.size(); ++i) {
-        const HNode &hn = oct.nodes[i];
-        DNode32 &dn = nodes32[i];
-        widen_radius(hn.bbox);
-        for (int a = 0; a < 3; ++a) {
-            dn.bmin[a] = f32_down(hn.bbox.mn[a] - centre[a]);
-            dn.bmax[a] = f32_up(hn.bbox.mx[a] - centre[a]);
-        }
-        if (hn.first_child >= 0) {
-            dn.link = ((uint32_t)hn.first_child << 8) | nodes[i].child_mask;
-            dn.aux = 0xFFFFFFFFu;
-        } else {
-            dn.link = (uint32_t)entries32.size();
-            dn.aux = (uint32_t)hn.entries.size();
-        }
-        for (int e : hn.entries) {
-            const HBox &pb = oct.prim_box[(size_t)e];
-            widen_radius(pb);
-            DEntry32 de;
-            for (int a = 0; a < 3; ++a) {
-                de.bmin[a] = f32_down(pb.mn[a] - centre[a]);
-                de.bmax[a] = f32_up(pb.mx[a] - centre[a]);
-            }
-            de.ref = ref_of_prim[(size_t)e];
-            de.pad = 0;
-            entries32.push_back(de);
-        }
-    }
-    // 16-wide box lists for the cooperative any-hit traversal
-    std::vector<RtxPrimBox> pboxes((size_t)n_fin);
-    for (int i = 0; i < n_fin; ++i) {
-        const HBox &pb = oct.prim_box[(size_t)i];
-        for (int a = 0; a < 3; ++a) { pboxes[(size_t)i].mn[a] = pb.mn[a]; pboxes[(size_t)i].mx[a] = pb.mx[a]; }
-        int32_t r = ref_of_prim[(size_t)i];
-        pboxes[(size_t)i].ref = r >= 0 ? (RTX_WREF_TRI | (uint32_t)r) : (RTX_WREF_SPHERE | (uint32_t)(~r));
-    }
-    std::vector<DWideChild> wide;
-    RtxWideStats wstats;
-    rtx_build_wide_bvh(pboxes, centre, wide, &wstats);
-    // k_shadow_coop's level stack (24 levels), queue entry bits, 23-bit prim index of a waiting pair
-    const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 26) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
+    lap("prim records");
     // images -> one RGBA8 atlas
     std::vector<DImage> images((size_t)d->n_images);
     std::vector<uint8_t> atlas;
@@ -927,15 +1118,96 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         if (m.glossiness > 2.220446049250313e-16) s->any_glossy = true;
     }
 
+    // everything that is ready goes to the device now, on the uploader's thread, while this thread builds the rest
     DScene &ds = s->d;
-    if ((st = upload(s.get(), nodes32, &ds.nodes32)) || (st = upload(s.get(), entries32, &ds.entries32)) ||
-        (st = upload(s.get(), wide, &ds.wide)) || (st = upload(s.get(), nodes, &ds.nodes)) || (st = upload(s.get(), leaf_refs, &ds.leaf_refs)) ||
-        (st = upload(s.get(), tris, &ds.tris)) || (st = upload(s.get(), shade, &ds.tri_shade)) ||
-        (st = upload(s.get(), spheres, &ds.spheres)) || (st = upload(s.get(), planes, &ds.planes)) ||
-        (st = upload(s.get(), materials, &ds.materials)) || (st = upload(s.get(), textures, &ds.textures)) ||
-        (st = upload(s.get(), images, &ds.images)) || (st = upload(s.get(), atlas, &ds.atlas)) ||
-        (st = upload(s.get(), s->lights, &ds.lights)))
-        return cleanup(st);
+    up.submit(tris.get(), n_tri, &ds.tris);
+    up.submit(shade.get(), n_tri, &ds.tri_shade);
+    up.submit(spheres.get(), n_sph, &ds.spheres);
+    up.submit(planes, &ds.planes);
+    up.submit(materials, &ds.materials);
+    up.submit(textures, &ds.textures);
+    up.submit(images, &ds.images);
+    up.submit(atlas, &ds.atlas);
+    up.submit(s->lights, &ds.lights);
+    // nodes + leaf entries (leaf_refs in the order of HostOctree::entries)
+    const size_t n_nodes = oct.nodes.size();
+    std::vector<DNode> nodes(n_nodes);
+    std::vector<int32_t> leaf_refs(oct.entries.size());
+    std::vector<uint8_t> nonempty(n_nodes, 0);
+    for (size_t i = n_nodes; i-- > 0;) {   // children have larger indices than their parent: one backward pass
+        const FNode &hn = oct.nodes[i];
+        bool ne = hn.ecount > 0;
+        if (hn.first_child >= 0)
+            for (int c = 0; c < 8; ++c) ne = ne || nonempty[(size_t)(hn.first_child + c)];
+        nonempty[i] = ne ? 1 : 0;
+    }
+    int n_interior = 0, max_entries = 0;
+    for (size_t i = 0; i < n_nodes; ++i) {
+        if (oct.nodes[i].first_child >= 0) ++n_interior;
+        max_entries = std::max(max_entries, oct.nodes[i].ecount);
+    }
+    {
+        const size_t chunk = 16384, n_chunks = (n_nodes + chunk - 1) / chunk;
+        pool.run(n_chunks, [&](size_t t) {
+            for (size_t i = t * chunk; i < std::min(n_nodes, (t + 1) * chunk); ++i) {
+                const FNode &hn = oct.nodes[i];
+                DNode &dn = nodes[i];
+                for (int a = 0; a < 3; ++a) { dn.bmin[a] = hn.bbox.mn[a]; dn.bmax[a] = hn.bbox.mx[a]; }
+                dn.first_child = hn.first_child;
+                dn.entry_begin = hn.ebegin;
+                dn.entry_count = hn.ecount;
+                dn.child_mask = 0;
+                if (hn.first_child >= 0)
+                    for (int c = 0; c < 8; ++c)
+                        if (nonempty[(size_t)(hn.first_child + c)]) dn.child_mask |= 1u << c;
+            }
+        });
+        const size_t n_e = leaf_refs.size(), e_chunks = (n_e + chunk - 1) / chunk;
+        pool.run(e_chunks, [&](size_t t) {
+            for (size_t e = t * chunk; e < std::min(n_e, (t + 1) * chunk); ++e) leaf_refs[e] = ref_of_prim[(size_t)oct.entries[e]];
+        });
+    }
+    up.submit(nodes, &ds.nodes);
+    up.submit(leaf_refs, &ds.leaf_refs);
+    lap("linearise nodes");
+    // The conservative f32 twins (DNode32 / DEntry32: boxes relative to the root centre, rounded outward) are derived ON THE DEVICE
+    // from the uploaded f64 records (rtxk_build_twins below): nothing of them is built or copied by the host.
+    // Every box lies inside the root's (the union of the prim boxes; child boxes can leave it by an ulp of rounding).
+    double centre[3], radius = 0.0;
+    for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (oct.nodes[0].bbox.mn[a] + oct.nodes[0].bbox.mx[a]);
+    for (int a = 0; a < 3; ++a)
+        radius = std::max(radius, std::max(std::fabs(oct.nodes[0].bbox.mn[a] - centre[a]), std::fabs(oct.nodes[0].bbox.mx[a] - centre[a])));
+    radius *= 1.0 + 1.0e-12;
+    // 16-wide box lists for the cooperative any-hit traversal
+    std::vector<RtxPrimBox> pboxes((size_t)n_fin);
+    for (int i = 0; i < n_fin; ++i) {
+        const HBox &pb = oct.prim_box[(size_t)i];
+        for (int a = 0; a < 3; ++a) { pboxes[(size_t)i].mn[a] = pb.mn[a]; pboxes[(size_t)i].mx[a] = pb.mx[a]; }
+        int32_t r = ref_of_prim[(size_t)i];
+        pboxes[(size_t)i].ref = r >= 0 ? (RTX_WREF_TRI | (uint32_t)r) : (RTX_WREF_SPHERE | (uint32_t)(~r));
+    }
+    std::vector<DWideChild> wide;
+    RtxWideStats wstats;
+    rtx_build_wide_bvh(pboxes, centre, wide, &wstats, pool);
+    // k_shadow_coop's level stack (24 levels), queue entry bits, 23-bit prim index of a waiting pair
+    const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 26) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
+    lap("wide box lists (SAH)");
+    up.submit(wide, &ds.wide);
+    if ((st = up.finish(s.get()))) return cleanup(st);
+    DNode32 *d_nodes32 = nullptr;
+    DEntry32 *d_entries32 = nullptr;
+    if ((st = dev_alloc(&d_nodes32, n_nodes))) return cleanup(st);
+    s->allocs.push_back(d_nodes32);
+    if ((st = dev_alloc(&d_entries32, leaf_refs.size()))) return cleanup(st);
+    s->allocs.push_back(d_entries32);
+    s->info.device_bytes += (int64_t)(std::max<size_t>(n_nodes, 1) * sizeof(DNode32) + std::max<size_t>(leaf_refs.size(), 1) * sizeof(DEntry32));
+    ds.nodes32 = d_nodes32;
+    ds.entries32 = d_entries32;
+    lap("rest of the uploads");
+    rtxk_build_twins(nullptr, ds.nodes, d_nodes32, (int64_t)n_nodes, ds.leaf_refs, ds.tris, ds.spheres, d_entries32, (int64_t)leaf_refs.size(), centre);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipGetLastError());
+    lap("f32 twins (device)");
     if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane octree walk
     s->n_materials = d->n_materials;
     s->n_textures = d->n_textures;
@@ -1107,12 +1379,14 @@ rtx_status rtx_shade_probe(rtx_scene *s, int32_t which, int64_t n, const double 
 // entries are finite-prim ids.  Pass NULL arrays to get the sizes only.
 rtx_status rtx_octree_dump(const rtx_scene_desc *d, int32_t *depth, int64_t *n_nodes, int64_t *n_entries, double *bbox_out,
                            int32_t *shape_out, int32_t *entries_out) {
+    const unsigned n_threads_env = build_threads();
+    RtxPool pool(std::max(1u, n_threads_env));
     Flat fl;
     rtx_status st = flatten(d, fl);
     if (st) return st;
+    build_octree(fl, n_threads_env ? &pool : nullptr);
     const HostOctree &oct = fl.oct;
-    int64_t ne = 0;
-    for (const HNode &n : oct.nodes) ne += (int64_t)n.entries.size();
+    int64_t ne = (int64_t)oct.entries.size();
     if (depth) *depth = oct.depth;
     if (n_nodes) *n_nodes = (int64_t)oct.nodes.size();
     if (n_entries) *n_entries = ne;
@@ -1121,12 +1395,12 @@ rtx_status rtx_octree_dump(const rtx_scene_desc *d, int32_t *depth, int64_t *n_n
     while (!stack.empty()) {
         int ni = stack.back();
         stack.pop_back();
-        const HNode &n = oct.nodes[(size_t)ni];
+        const FNode &n = oct.nodes[(size_t)ni];
         for (int a = 0; a < 3; ++a) *bbox_out++ = n.bbox.mn[a];
         for (int a = 0; a < 3; ++a) *bbox_out++ = n.bbox.mx[a];
         *shape_out++ = n.first_child >= 0 ? 8 : 0;
-        *shape_out++ = (int32_t)n.entries.size();
-        for (int e : n.entries) *entries_out++ = e;
+        *shape_out++ = (int32_t)n.ecount;
+        for (int e = 0; e < n.ecount; ++e) *entries_out++ = oct.entries[(size_t)(n.ebegin + e)];
         if (n.first_child >= 0)
             for (int c = 7; c >= 0; --c) stack.push_back(n.first_child + c);
     }

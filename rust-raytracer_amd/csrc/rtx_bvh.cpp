@@ -14,6 +14,13 @@
 // from a binary node's two children and keeps replacing the internal child of largest surface
 // area by its two children until it holds RTX_WIDE children or only primitives.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <array>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -26,6 +33,7 @@ struct BNode {
     double mn[3], mx[3];
     int left = -1, right = -1;   // binary children, or
     int prim = -1;               // leaf: index into the prim list
+    double sa = 0.0;             // surface area of the box (the collapse picks by it)
 };
 
 inline double area(const double *mn, const double *mx) {
@@ -55,112 +63,214 @@ inline float f32_up(double x) {
     return f;
 }
 
+constexpr int BINS = 16;
+// what one pass over (a part of) a node's prims gathers for the binned SAH split
+struct BinSet {
+    int cnt[3][BINS];
+    double bmn[3][BINS][3], bmx[3][BINS][3];
+    void clear() {
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < BINS; ++b) { cnt[a][b] = 0; reset(bmn[a][b], bmx[a][b]); }
+    }
+    void merge(const BinSet &o) {
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < BINS; ++b) {
+                if (!o.cnt[a][b]) continue;
+                cnt[a][b] += o.cnt[a][b];
+                grow(bmn[a][b], bmx[a][b], o.bmn[a][b], o.bmx[a][b]);
+            }
+    }
+};
+
+// Binned-SAH binary BVH.  The build is the same whatever the thread count: a node's split depends only on its own prim range.
+// Large ranges (the top of the tree) are binned by all threads together; once a range is small its whole subtree is one task.
 struct Builder {
     const std::vector<RtxPrimBox> &prims;
     std::vector<int> order;      // permutation of prim indices, partitioned in place
     std::vector<BNode> nodes;
-    static constexpr int BINS = 16;
+    RtxPool &pool;
+    unsigned n_threads;
+    static constexpr int PAR_MIN = 8192;   // ranges at least this long are split with parallel passes; shorter ones are subtree tasks
 
-    explicit Builder(const std::vector<RtxPrimBox> &p) : prims(p), order(p.size()) {
+    Builder(const std::vector<RtxPrimBox> &p, RtxPool &pl) : prims(p), order(p.size()), pool(pl), n_threads(pl.size()) {
         for (size_t i = 0; i < p.size(); ++i) order[i] = (int)i;
-        nodes.reserve(p.size() * 2 + 1);
     }
-    // builds the subtree over order[begin, end); returns its node index
-    int build(int begin, int end) {
+    static int bin_of(const RtxPrimBox &p, int a, double cmn, double scale) {
+        int b = (int)((0.5 * (p.mn[a] + p.mx[a]) - cmn) * scale);
+        return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+    }
+    void bounds_of(int begin, int end, double *mn, double *mx, double *cmn, double *cmx) const {
+        reset(mn, mx);
+        reset(cmn, cmx);
+        for (int i = begin; i < end; ++i) {
+            const RtxPrimBox &p = prims[(size_t)order[(size_t)i]];
+            grow(mn, mx, p.mn, p.mx);
+            double c[3] = {0.5 * (p.mn[0] + p.mx[0]), 0.5 * (p.mn[1] + p.mx[1]), 0.5 * (p.mn[2] + p.mx[2])};
+            grow(cmn, cmx, c, c);
+        }
+    }
+    void bin_range(int begin, int end, const double *cmn, const double *cmx, BinSet &bs) const {
+        double scale[3];
+        bool use[3];
+        for (int a = 0; a < 3; ++a) {
+            double ext = cmx[a] - cmn[a];
+            use[a] = ext > 0.0;
+            scale[a] = use[a] ? (double)BINS / ext : 0.0;
+        }
+        for (int i = begin; i < end; ++i) {
+            const RtxPrimBox &p = prims[(size_t)order[(size_t)i]];
+            for (int a = 0; a < 3; ++a) {
+                if (!use[a]) continue;
+                int b = bin_of(p, a, cmn[a], scale[a]);
+                ++bs.cnt[a][b];
+                grow(bs.bmn[a][b], bs.bmx[a][b], p.mn, p.mx);
+            }
+        }
+    }
+    // splits order[begin, end) (n >= 2) and returns the first index of the right part; nd receives the node's box
+    int split(int begin, int end, BNode &nd, bool parallel) {
+        const int n = end - begin;
+        double cmn[3], cmx[3];
+        BinSet bs;
+        bs.clear();
+        if (!parallel) {
+            bounds_of(begin, end, nd.mn, nd.mx, cmn, cmx);
+            bin_range(begin, end, cmn, cmx, bs);
+        } else {
+            const int parts = (int)n_threads * 4, len = (n + parts - 1) / parts;
+            std::vector<std::array<double, 12>> pb((size_t)parts);
+            pool.run((size_t)parts, [&](size_t t) {
+                int b0 = begin + (int)t * len, b1 = std::min(end, b0 + len);
+                double *q = pb[t].data();
+                bounds_of(b0, std::max(b0, b1), q, q + 3, q + 6, q + 9);
+            });
+            reset(nd.mn, nd.mx);
+            reset(cmn, cmx);
+            for (int t = 0; t < parts; ++t) {
+                grow(nd.mn, nd.mx, pb[(size_t)t].data(), pb[(size_t)t].data() + 3);
+                grow(cmn, cmx, pb[(size_t)t].data() + 6, pb[(size_t)t].data() + 9);
+            }
+            std::vector<BinSet> part((size_t)parts);
+            pool.run((size_t)parts, [&](size_t t) {
+                int b0 = begin + (int)t * len, b1 = std::min(end, b0 + len);
+                part[t].clear();
+                if (b0 < b1) bin_range(b0, b1, cmn, cmx, part[t]);
+            });
+            for (int t = 0; t < parts; ++t) bs.merge(part[(size_t)t]);
+        }
+        // binned SAH over the three axes
+        int best_axis = -1, best_split = -1;
+        double best_cost = std::numeric_limits<double>::infinity();
+        for (int a = 0; a < 3; ++a) {
+            if (!(cmx[a] - cmn[a] > 0.0)) continue;
+            double rarea[BINS];
+            int rcnt[BINS];
+            double amn[3], amx[3];
+            reset(amn, amx);
+            int c = 0;
+            for (int b = BINS - 1; b > 0; --b) {
+                if (bs.cnt[a][b]) grow(amn, amx, bs.bmn[a][b], bs.bmx[a][b]);
+                c += bs.cnt[a][b];
+                rarea[b] = c ? area(amn, amx) : 0.0;
+                rcnt[b] = c;
+            }
+            reset(amn, amx);
+            c = 0;
+            for (int b = 0; b < BINS - 1; ++b) {
+                if (bs.cnt[a][b]) grow(amn, amx, bs.bmn[a][b], bs.bmx[a][b]);
+                c += bs.cnt[a][b];
+                if (c == 0 || rcnt[b + 1] == 0) continue;
+                double cost = area(amn, amx) * c + rarea[b + 1] * rcnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) {
+            mid = begin + n / 2;   // all centroids coincide: split the list in half
+        } else {
+            const int a = best_axis;
+            const double scale = (double)BINS / (cmx[a] - cmn[a]), c0 = cmn[a];
+            auto it = std::partition(order.begin() + begin, order.begin() + end,
+                                     [&](int pi) { return bin_of(prims[(size_t)pi], a, c0, scale) <= best_split; });
+            mid = (int)(it - order.begin());
+            if (mid == begin || mid == end) mid = begin + n / 2;
+        }
+        return mid;
+    }
+    void leaf(int begin, BNode &nd) const {
+        const RtxPrimBox &p = prims[(size_t)order[(size_t)begin]];
+        for (int a = 0; a < 3; ++a) { nd.mn[a] = p.mn[a]; nd.mx[a] = p.mx[a]; }
+        nd.prim = order[(size_t)begin];
+    }
+    // the subtree over order[begin, end) into `out` (out[0] = its root; children by local index), one thread
+    void build_local(std::vector<BNode> &out, int begin, int end) {
         struct Task { int node, begin, end; };
         std::vector<Task> stack;
-        int root = (int)nodes.size();
-        nodes.emplace_back();
-        stack.push_back({root, begin, end});
+        out.emplace_back();
+        stack.push_back({0, begin, end});
         while (!stack.empty()) {
             Task t = stack.back();
             stack.pop_back();
             BNode nd;
-            reset(nd.mn, nd.mx);
-            double cmn[3], cmx[3];
-            reset(cmn, cmx);
-            for (int i = t.begin; i < t.end; ++i) {
-                const RtxPrimBox &p = prims[(size_t)order[(size_t)i]];
-                grow(nd.mn, nd.mx, p.mn, p.mx);
-                double c[3] = {0.5 * (p.mn[0] + p.mx[0]), 0.5 * (p.mn[1] + p.mx[1]), 0.5 * (p.mn[2] + p.mx[2])};
-                grow(cmn, cmx, c, c);
-            }
-            int n = t.end - t.begin;
-            if (n == 1) {
-                nd.prim = order[(size_t)t.begin];
-                nodes[(size_t)t.node] = nd;
+            if (t.end - t.begin == 1) {
+                leaf(t.begin, nd);
+                out[(size_t)t.node] = nd;
                 continue;
             }
-            // binned SAH over the three axes
-            int best_axis = -1, best_split = -1;
-            double best_cost = std::numeric_limits<double>::infinity();
-            for (int a = 0; a < 3; ++a) {
-                double ext = cmx[a] - cmn[a];
-                if (!(ext > 0.0)) continue;
-                int cnt[BINS] = {0};
-                double bmn[BINS][3], bmx[BINS][3];
-                for (int b = 0; b < BINS; ++b) reset(bmn[b], bmx[b]);
-                double scale = (double)BINS / ext;
-                for (int i = t.begin; i < t.end; ++i) {
-                    const RtxPrimBox &p = prims[(size_t)order[(size_t)i]];
-                    int b = (int)((0.5 * (p.mn[a] + p.mx[a]) - cmn[a]) * scale);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    ++cnt[b];
-                    grow(bmn[b], bmx[b], p.mn, p.mx);
-                }
-                double rarea[BINS];
-                int rcnt[BINS];
-                double amn[3], amx[3];
-                reset(amn, amx);
-                int c = 0;
-                for (int b = BINS - 1; b > 0; --b) {
-                    if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
-                    c += cnt[b];
-                    rarea[b] = c ? area(amn, amx) : 0.0;
-                    rcnt[b] = c;
-                }
-                reset(amn, amx);
-                c = 0;
-                for (int b = 0; b < BINS - 1; ++b) {
-                    if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
-                    c += cnt[b];
-                    if (c == 0 || rcnt[b + 1] == 0) continue;
-                    double cost = area(amn, amx) * c + rarea[b + 1] * rcnt[b + 1];
-                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b; }
-                }
+            int mid = split(t.begin, t.end, nd, false);
+            nd.sa = area(nd.mn, nd.mx);
+            nd.left = (int)out.size();
+            out.emplace_back();
+            nd.right = (int)out.size();
+            out.emplace_back();
+            out[(size_t)t.node] = nd;
+            stack.push_back({nd.left, t.begin, mid});
+            stack.push_back({nd.right, mid, t.end});
+        }
+    }
+    // builds the tree over all prims; returns the root's index in `nodes`
+    int build() {
+        struct Task { int node, begin, end; };
+        std::vector<Task> top, subtree;
+        nodes.clear();
+        nodes.emplace_back();
+        top.push_back({0, 0, (int)prims.size()});
+        while (!top.empty()) {   // the large ranges, one after the other, each with all threads
+            Task t = top.back();
+            top.pop_back();
+            if (t.end - t.begin < PAR_MIN || n_threads == 1) {
+                subtree.push_back(t);
+                continue;
             }
-            int mid;
-            if (best_axis < 0) {
-                mid = t.begin + n / 2;   // all centroids coincide: split the list in half
-            } else {
-                double ext = cmx[best_axis] - cmn[best_axis];
-                double scale = (double)BINS / ext;
-                int a = best_axis;
-                auto it = std::partition(order.begin() + t.begin, order.begin() + t.end, [&](int pi) {
-                    const RtxPrimBox &p = prims[(size_t)pi];
-                    int b = (int)((0.5 * (p.mn[a] + p.mx[a]) - cmn[a]) * scale);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    return b <= best_split;
-                });
-                mid = (int)(it - order.begin());
-                if (mid == t.begin || mid == t.end) mid = t.begin + n / 2;
-            }
+            BNode nd;
+            int mid = split(t.begin, t.end, nd, true);
+            nd.sa = area(nd.mn, nd.mx);
             nd.left = (int)nodes.size();
             nodes.emplace_back();
             nd.right = (int)nodes.size();
             nodes.emplace_back();
             nodes[(size_t)t.node] = nd;
-            stack.push_back({nd.left, t.begin, mid});
-            stack.push_back({nd.right, mid, t.end});
+            top.push_back({nd.left, t.begin, mid});
+            top.push_back({nd.right, mid, t.end});
         }
-        return root;
+        std::vector<std::vector<BNode>> local(subtree.size());
+        pool.run(subtree.size(), [&](size_t i) { build_local(local[i], subtree[i].begin, subtree[i].end); });
+        for (size_t i = 0; i < subtree.size(); ++i) {   // local node j > 0 becomes base + j - 1, local node 0 is nodes[subtree[i].node]
+            const int base = (int)nodes.size() - 1;
+            std::vector<BNode> &L = local[i];
+            for (BNode &b : L)
+                if (b.prim < 0) { b.left += base; b.right += base; }
+            nodes[(size_t)subtree[i].node] = L[0];
+            nodes.insert(nodes.end(), L.begin() + 1, L.end());
+        }
+        return 0;
     }
 };
 
 } // namespace
 
 void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
-                        RtxWideStats *stats) {
+                        RtxWideStats *stats, RtxPool &pool) {
     out.clear();
     auto add_node = [&]() {   // appends RTX_WIDE empty children, returns the node index
         DWideChild c;
@@ -177,19 +287,25 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
         if (stats) { stats->nodes = 1; stats->depth = 1; }
         return;
     }
-    Builder b(prims);
-    int broot = b.build(0, (int)prims.size());
+    const bool timing = std::getenv("RTX_BUILD_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    Builder b(prims, pool);
+    int broot = b.build();
+    if (timing) std::fprintf(stderr, "    SAH binary tree %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const std::vector<BNode> &bn = b.nodes;
 
     struct Task { uint32_t wide; int bnode; int depth; };
     std::vector<Task> stack;
+    std::vector<int> kids;
+    kids.reserve(RTX_WIDE + 1);
+    out.reserve((prims.size() / 6 + 16) * RTX_WIDE);
     stack.push_back({add_node(), broot, 1});
     int max_depth = 0;
     while (!stack.empty()) {
         Task t = stack.back();
         stack.pop_back();
         // collect up to RTX_WIDE children by opening the largest internal child first
-        std::vector<int> kids;
+        kids.clear();
         if (bn[(size_t)t.bnode].prim >= 0) kids.push_back(t.bnode);   // single-prim scene
         else { kids.push_back(bn[(size_t)t.bnode].left); kids.push_back(bn[(size_t)t.bnode].right); }
         for (;;) {
@@ -199,8 +315,7 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
             for (size_t i = 0; i < kids.size(); ++i) {
                 const BNode &k = bn[(size_t)kids[i]];
                 if (k.prim >= 0) continue;
-                double ar = area(k.mn, k.mx);
-                if (ar > pa) { pa = ar; pick = (int)i; }
+                if (k.sa > pa) { pa = k.sa; pick = (int)i; }
             }
             if (pick < 0) break;
             int k = kids[(size_t)pick];

@@ -200,6 +200,10 @@ void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double
                   int32_t *prim_id, double *t_out, uint32_t flags);
 void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *target,
                           double *out, uint32_t flags);
+// scene build, on the device: the conservative f32 twins of the octree (DNode32 per node, DEntry32 per leaf entry: the entry's prim box
+// recomputed from the prim record) from the uploaded f64 records; boxes relative to `centre`, rounded outward
+void rtxk_build_twins(rtx_stream_t stream, const DNode *nodes, DNode32 *nodes32, int64_t n_nodes, const int32_t *leaf_refs,
+                      const DTri *tris, const DSphere *spheres, DEntry32 *entries32, int64_t n_entries, const double centre[3]);
 void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out);
 // sets counters->pool_tail, clears counters->overflow (a one-thread kernel: the allocation-free entry point has no pinned
 // host buffer to copy them from)

@@ -2309,6 +2309,58 @@ __global__ void k_set_pool_tail(DCounters *counters, uint32_t pool_tail) {
     counters->pool_tail = pool_tail;
     counters->overflow = 0u;
 }
+// Scene build on the device: DNode32 / DEntry32 (see rtx_device.h) from the f64 records.  v_cvt_f32_f64 with directed rounding
+// (toward -inf for a box's lower corner, toward +inf for its upper corner) is the outward rounding the conservative tests rely on.
+__global__ void __launch_bounds__(RTX_BLOCK) k_build_nodes32(const DNode *nodes, DNode32 *out, int64_t n, double cx, double cy, double cz) {
+    const int64_t i = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const DNode nd = nodes[i];
+    DNode32 o;
+    o.bmin[0] = __double2float_rd(nd.bmin[0] - cx); o.bmin[1] = __double2float_rd(nd.bmin[1] - cy); o.bmin[2] = __double2float_rd(nd.bmin[2] - cz);
+    o.bmax[0] = __double2float_ru(nd.bmax[0] - cx); o.bmax[1] = __double2float_ru(nd.bmax[1] - cy); o.bmax[2] = __double2float_ru(nd.bmax[2] - cz);
+    if (nd.first_child >= 0) {
+        o.link = ((uint32_t)nd.first_child << 8) | nd.child_mask;
+        o.aux = 0xFFFFFFFFu;
+    } else {
+        o.link = (uint32_t)nd.entry_begin;
+        o.aux = (uint32_t)nd.entry_count;
+    }
+    out[i] = o;
+}
+__global__ void __launch_bounds__(RTX_BLOCK) k_build_entries32(const int32_t *leaf_refs, const DTri *tris, const DSphere *spheres, DEntry32 *out,
+                                                               int64_t n, double cx, double cy, double cz) {
+    const int64_t i = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int ref = leaf_refs[i];
+    double mn[3], mx[3];
+    if (ref >= 0) {                                                                      // triangle.rs:102-106
+        const DTri &t = tris[ref];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fmin(fmin(t.v[a], t.v[3 + a]), t.v[6 + a]);
+            mx[a] = fmax(fmax(t.v[a], t.v[3 + a]), t.v[6 + a]);
+        }
+    } else {                                                                             // sphere.rs:18-33
+        const DSphere &sp = spheres[~ref];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = sp.c[a] - sp.r; mx[a] = sp.c[a] + sp.r; }
+    }
+    DEntry32 o;
+    o.bmin[0] = __double2float_rd(mn[0] - cx); o.bmin[1] = __double2float_rd(mn[1] - cy); o.bmin[2] = __double2float_rd(mn[2] - cz);
+    o.bmax[0] = __double2float_ru(mx[0] - cx); o.bmax[1] = __double2float_ru(mx[1] - cy); o.bmax[2] = __double2float_ru(mx[2] - cz);
+    o.ref = ref;
+    o.pad = 0;
+    out[i] = o;
+}
+void rtxk_build_twins(rtx_stream_t stream, const DNode *nodes, DNode32 *nodes32, int64_t n_nodes, const int32_t *leaf_refs,
+                      const DTri *tris, const DSphere *spheres, DEntry32 *entries32, int64_t n_entries, const double centre[3]) {
+    if (n_nodes > 0)
+        hipLaunchKernelGGL(k_build_nodes32, dim3(grid_for((uint64_t)n_nodes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, nodes, nodes32, n_nodes,
+                           centre[0], centre[1], centre[2]);
+    if (n_entries > 0)
+        hipLaunchKernelGGL(k_build_entries32, dim3(grid_for((uint64_t)n_entries)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, leaf_refs, tris,
+                           spheres, entries32, n_entries, centre[0], centre[1], centre[2]);
+}
 void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_shade_probe, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, which, n, in, out);

@@ -308,7 +308,7 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     rays = np.zeros(5, dtype=np.float64)
-    ms_dev = []
+    ms_dev, ms_call = [], []
     last = {}
 
     def render_frame(k, t):
@@ -319,6 +319,7 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
         st = scene.render_device(cam, opt, rgba.data_ptr(), None, stream, want_stats=True)
         rays[:] += [st.rays_primary, st.rays_reflect, st.rays_gloss, st.rays_refract, st.rays_shadow]
         ms_dev.append(st.ms_device)
+        ms_call.append(st.ms_total)
         return rgba if comm_dev is dev else rgba.cpu()
 
     def on_frame(k, t, frame):      # rank 0: where the reference's writer thread would write {output_file}{:06}.ppm
@@ -334,6 +335,7 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
         sh.animate(frames[:world], rank, world, dist, render_frame, None)
     rays[:] = 0
     del ms_dev[:]
+    del ms_call[:]
     barrier()
     t_start = time.perf_counter()
     n_mine = sh.animate(frames, rank, world, dist, render_frame, on_frame)
@@ -362,7 +364,8 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
                                        refl, refr, world, world),
                           "triangles": int(named.n_triangles), "octree_nodes": int(info.n_nodes), "scene_build_upload_s": round(build_s, 3)},
                "frames": len(frames), "frames_rank0": int(n_mine), "ms_per_frame_node": elapsed / len(frames) * 1e3,
-               "ms_per_frame_rank0_device": sum(ms_dev) / max(1, len(ms_dev)), "frames_per_s_node": len(frames) / elapsed,
+               "ms_per_frame_rank0_device": sum(ms_dev) / max(1, len(ms_dev)),
+               "ms_per_frame_rank0_call": sum(ms_call) / max(1, len(ms_call)), "frames_per_s_node": len(frames) / elapsed,
                "rays_per_frame": total_rays / len(frames), "last_frame_gathered": last.get("k")}
         print(json.dumps(out), flush=True)
     scene.close()

@@ -34,6 +34,12 @@ struct BNode {
     int left = -1, right = -1;   // binary children, or
     int prim = -1;               // leaf: index into the prim list
     double sa = 0.0;             // surface area of the box (the collapse picks by it)
+    // collapse DP (see collapse_costs): cost[i-1] = least expected number of wide-node visits below this node when its subtree
+    // is handed i child slots of a wide node; how[i-1] = 0: as with i - 1 slots, k > 0: left child gets k slots, right i - k;
+    // how[0] is unused (one slot: the node becomes a wide node of its own, or is a primitive)
+    // own = the split of the RTX_WIDE slots between the two children when this node is a wide node itself
+    float cost[RTX_WIDE];
+    uint8_t how[RTX_WIDE], own;
 };
 
 inline double area(const double *mn, const double *mx) {
@@ -197,6 +203,42 @@ struct Builder {
         }
         return mid;
     }
+    // Collapse DP after Ylitie et al. 2017 (wide BVHs by dynamic programming), for the cost the cooperative walk pays: a visit of a
+    // wide node costs the same whatever it holds (16 lanes test its 16 slots at once), and a primitive is queued iff the beam touches
+    // its own box, whatever the structure above it; so the collapse minimises the expected number of NODE VISITS, sum of area(node)
+    // over wide nodes.  v[] must be in an order where children come after their parents (true for every vector built here).
+    static void collapse_costs(std::vector<BNode> &v, size_t first, size_t last) {
+        for (size_t idx = last; idx-- > first;) {
+            BNode &n = v[idx];
+            if (n.prim >= 0) {
+                for (int i = 0; i < RTX_WIDE; ++i) { n.cost[i] = 0.0f; n.how[i] = 0; }
+                n.own = 0;
+                continue;
+            }
+            const BNode &l = v[(size_t)n.left], &r = v[(size_t)n.right];
+            float d[RTX_WIDE + 1];
+            uint8_t dk[RTX_WIDE + 1];
+            for (int j = 2; j <= RTX_WIDE; ++j) {
+                float best = std::numeric_limits<float>::infinity();
+                int bk = 1;
+                for (int k = 1; k < j; ++k) {
+                    float c = l.cost[k - 1] + r.cost[j - k - 1];
+                    if (c < best) { best = c; bk = k; }
+                }
+                d[j] = best;
+                dk[j] = (uint8_t)bk;
+            }
+            static const double infl = std::getenv("RTX_BVH_INFLATE") ? std::atof(std::getenv("RTX_BVH_INFLATE")) : 0.0;
+            const double ex = n.mx[0] - n.mn[0] + infl, ey = n.mx[1] - n.mn[1] + infl, ez = n.mx[2] - n.mn[2] + infl;
+            n.cost[0] = (float)(2.0 * (ex * ey + ey * ez + ez * ex)) + d[RTX_WIDE];
+            n.how[0] = 0;
+            n.own = dk[RTX_WIDE];
+            for (int i = 2; i <= RTX_WIDE; ++i) {
+                if (d[i] < n.cost[i - 2]) { n.cost[i - 1] = d[i]; n.how[i - 1] = dk[i]; }
+                else { n.cost[i - 1] = n.cost[i - 2]; n.how[i - 1] = 0; }
+            }
+        }
+    }
     void leaf(int begin, BNode &nd) const {
         const RtxPrimBox &p = prims[(size_t)order[(size_t)begin]];
         for (int a = 0; a < 3; ++a) { nd.mn[a] = p.mn[a]; nd.mx[a] = p.mx[a]; }
@@ -227,6 +269,7 @@ struct Builder {
             stack.push_back({nd.left, t.begin, mid});
             stack.push_back({nd.right, mid, t.end});
         }
+        collapse_costs(out, 0, out.size());
     }
     // builds the tree over all prims; returns the root's index in `nodes`
     int build() {
@@ -253,6 +296,9 @@ struct Builder {
             top.push_back({nd.left, t.begin, mid});
             top.push_back({nd.right, mid, t.end});
         }
+        const size_t n_top = nodes.size();
+        std::vector<char> is_subtree_root(n_top, 0);
+        for (const Task &t : subtree) is_subtree_root[(size_t)t.node] = 1;
         std::vector<std::vector<BNode>> local(subtree.size());
         pool.run(subtree.size(), [&](size_t i) { build_local(local[i], subtree[i].begin, subtree[i].end); });
         for (size_t i = 0; i < subtree.size(); ++i) {   // local node j > 0 becomes base + j - 1, local node 0 is nodes[subtree[i].node]
@@ -263,6 +309,8 @@ struct Builder {
             nodes[(size_t)subtree[i].node] = L[0];
             nodes.insert(nodes.end(), L.begin() + 1, L.end());
         }
+        for (size_t idx = n_top; idx-- > 0;)   // the top nodes (split with parallel passes), children before parents
+            if (!is_subtree_root[idx]) collapse_costs(nodes, idx, idx + 1);
         return 0;
     }
 };
@@ -293,6 +341,7 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
     int broot = b.build();
     if (timing) std::fprintf(stderr, "    SAH binary tree %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const std::vector<BNode> &bn = b.nodes;
+    const bool greedy = std::getenv("RTX_BVH_GREEDY") != nullptr;
 
     struct Task { uint32_t wide; int bnode; int depth; };
     std::vector<Task> stack;
@@ -304,11 +353,28 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
     while (!stack.empty()) {
         Task t = stack.back();
         stack.pop_back();
-        // collect up to RTX_WIDE children by opening the largest internal child first
         kids.clear();
         if (bn[(size_t)t.bnode].prim >= 0) kids.push_back(t.bnode);   // single-prim scene
-        else { kids.push_back(bn[(size_t)t.bnode].left); kids.push_back(bn[(size_t)t.bnode].right); }
-        for (;;) {
+        else if (!greedy) {
+            // the children the collapse DP chose (Builder::collapse_costs): least expected number of node visits
+            struct Open { int node, slots; };
+            std::vector<Open> open;
+            const BNode &w = bn[(size_t)t.bnode];
+            open.push_back({w.right, RTX_WIDE - (int)w.own});
+            open.push_back({w.left, (int)w.own});
+            while (!open.empty()) {
+                Open o = open.back();
+                open.pop_back();
+                const BNode &k = bn[(size_t)o.node];
+                while (o.slots > 1 && k.prim < 0 && k.how[o.slots - 1] == 0) --o.slots;   // no better than with one slot fewer
+                if (k.prim >= 0 || o.slots == 1) { kids.push_back(o.node); continue; }      // a primitive, or a wide node of its own
+                const int kl = (int)k.how[o.slots - 1];
+                open.push_back({k.right, o.slots - kl});
+                open.push_back({k.left, kl});
+            }
+        } else { kids.push_back(bn[(size_t)t.bnode].left); kids.push_back(bn[(size_t)t.bnode].right); }
+        // (RTX_BVH_GREEDY: up to RTX_WIDE children by opening the largest internal child first)
+        for (; greedy;) {
             if ((int)kids.size() >= RTX_WIDE) break;
             int pick = -1;
             double pa = -1.0;

@@ -1339,7 +1339,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
     __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : 1];
     init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
+    const uint32_t tries_shift = (uint32_t)__ffs((int)tries) - 1u;   // (no 64-bit division for the usual try counts)
+    uint32_t group = pow2_tries ? (uint32_t)(gid >> tries_shift) : (uint32_t)(gid / tries);
+    uint32_t k = pow2_tries ? ((uint32_t)gid & (tries - 1u)) : (uint32_t)(gid % tries);
     bool valid = group < n_groups;
     size_t qc = sq.cap;
     V3 hp = v3(0, 0, 0), w = v3(0, 0, 0);
@@ -1565,7 +1567,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     if (n_groups == 0xFFFFFFFFu) s_pad[threadIdx.x] = tries;
 #endif
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    uint32_t group = (uint32_t)(gid / tries), k = (uint32_t)(gid % tries);
+    // (a 64-bit division by a run-time value is ~40 instructions; the usual try counts are powers of two)
+    const uint32_t tries_shift = (uint32_t)__ffs((int)tries) - 1u;
+    uint32_t group = pow2_tries ? (uint32_t)(gid >> tries_shift) : (uint32_t)(gid / tries);
+    uint32_t k = pow2_tries ? ((uint32_t)gid & (tries - 1u)) : (uint32_t)(gid % tries);
     bool valid = group < n_groups;
     size_t qc = sq.cap;
     V3 hp = v3(0, 0, 0);
@@ -2105,8 +2110,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     uint32_t t2 = threadIdx.x;
     asm volatile("" : "+v"(t2));   // group / try index and loads afresh, not the prologue's values kept alive
     const uint64_t gid2 = (uint64_t)blockIdx.x * RTX_BLOCK + t2;
-    if (valid && !wide && (gid2 % tries == 0u || !pow2_tries)) {
-        const uint32_t g2 = (uint32_t)(gid2 / tries);
+    if (valid && !wide && (!pow2_tries || ((uint32_t)gid2 & (tries - 1u)) == 0u)) {
+        const uint32_t g2 = pow2_tries ? (uint32_t)(gid2 >> tries_shift) : (uint32_t)(gid2 / tries);
         const double *f = sq.f + (size_t)light * 6 * qc + g2;
         acc_add(acc, sq.sample[(size_t)light * qc + g2], v3(f[3 * qc], f[4 * qc], f[5 * qc]) * scale(v, inv_tries));   // renderer.rs:220,118
         if (MULTI) sq.sample[(size_t)light * qc + g2] = SHADOW_GROUP_EMPTY;   // done: the per-lane pass that follows skips it

@@ -104,6 +104,7 @@ int main(int argc, char **argv) {
     std::uniform_real_distribution<double> U(0.0, 1.0);
     for (int64_t li = 0; li < nl; ++li) {
         const double *L = &lights[(size_t)li * 4];
+        double by_depth[16] = {0}, by_fill[17] = {0};
         double s_nodes = 0, s_box = 0, s_exact = 0, s_queued = 0, s_occl = 0, s_steps = 0;
         for (int g = 0; g < groups; ++g) {
             // a surface point, area-weighted
@@ -127,10 +128,15 @@ int main(int argc, char **argv) {
             }
             // depth-first walk, children in slot order; "beam touches box" = some live feeler's segment touches it
             std::vector<uint32_t> stack{0u};
+            std::vector<int> dstack{0};
             int live = 16, visits = 0;
             while (!stack.empty() && live > 0) {
                 uint32_t nd = stack.back();
                 stack.pop_back();
+                int dep = dstack.back();
+                dstack.pop_back();
+                by_depth[dep < 15 ? dep : 15] += 1;
+                { int fc = 0; for (int s = 0; s < RTX_WIDE; ++s) fc += (wide[(size_t)nd * RTX_WIDE + s].ref & RTX_WREF_KIND) != RTX_WREF_EMPTY; by_fill[fc] += 1; }
                 ++visits;
                 std::vector<uint32_t> kids;
                 for (int s = 0; s < RTX_WIDE; ++s) {
@@ -155,7 +161,7 @@ int main(int argc, char **argv) {
                         }
                     }
                 }
-                for (size_t q = kids.size(); q-- > 0;) stack.push_back(kids[q]);
+                for (size_t q = kids.size(); q-- > 0;) { stack.push_back(kids[q]); dstack.push_back(dep + 1); }
             }
             s_nodes += visits;
             s_steps += (visits + 1) / 2;
@@ -164,6 +170,11 @@ int main(int argc, char **argv) {
         std::printf("light %lld: node visits per group %.2f (two-node steps %.2f), prims queued per group %.2f, own-box tests per feeler %.2f, "
                     "exact tests per feeler %.2f, occluded %.3f\n", (long long)li, s_nodes / groups, s_steps / groups, s_queued / groups,
                     s_box / groups / 16, s_exact / groups / 16, s_occl / groups / 16);
+        std::printf("  visits by depth:");
+        for (int d = 0; d < 10; ++d) std::printf(" %.2f", by_depth[d] / groups);
+        std::printf("\n  visits by fill:");
+        for (int d = 1; d <= 16; ++d) std::printf(" %.2f", by_fill[d] / groups);
+        std::printf("\n");
     }
     return 0;
 }

@@ -1586,8 +1586,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         key = sq.key[(size_t)light * qc + group];
     }
 
-    // the lane's own feeler, exactly as k_shadow builds it (renderer.rs:198-206)
-    Ray r = make_ray(v3(0, 0, 0), v3(0, 0, 1));
+    // the lane's own feeler, exactly as k_shadow builds it (renderer.rs:198-206), but for the inverse direction: this kernel needs
+    // 1 / d only for its conservative f32 tests, and takes it from v_rcp_f32 (1 ulp) instead of three f64 divisions.  The exact
+    // tests build their own ray (run_pairs, confirm pass); a feeler that starts outside the scene's cube (rare) pays for the f64
+    // inverse in root_entry.
+    Ray r;
+    r.ox = r.oy = r.oz = 0.0; r.dx = r.dy = 0.0; r.dz = 1.0;
     double distance_to_light = 0.0;
     if (valid) {
         const rtx_light &lt = sc.lights[light];
@@ -1599,22 +1603,36 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
             sampled = sampled + jitter;
         }
         V3 shadow_l = unit(sampled - hp);
-        r = make_ray(hp, shadow_l);
+        r.ox = hp.x; r.oy = hp.y; r.oz = hp.z;
+        r.dx = shadow_l.x; r.dy = shadow_l.y; r.dz = shadow_l.z;
         distance_to_light = len(sampled - hp);
     }
+    r.ix = r.iy = r.iz = 0.0; r.flip = 0u;   // (not used below)
 
     // ---- own ray in f32 (as traverse_ww) for the per-lane primitive box tests
-    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    RootEntry re;
+    re.t_shift = 0.0;
+    re.miss = false;
+    {
+        const double R = sc.radius * 1.000001;
+        const double ocx = r.ox - sc.centre[0], ocy = r.oy - sc.centre[1], ocz = r.oz - sc.centre[2];
+        if (!(fabs(ocx) <= R && fabs(ocy) <= R && fabs(ocz) <= R)) re = root_entry(sc, make_ray(v3(r.ox, r.oy, r.oz), v3(r.dx, r.dy, r.dz)), ocx, ocy, ocz);
+    }
     const double tsh = re.t_shift;   // f32 frame re-based to where the ray enters the scene's cube
     const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
-    const bool sx = r.sx, sy = r.sy, sz = r.sz;
-    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    // Ray.signs (ray.rs:35-39: 1 / d > 0) = d > 0 for every feeler that walks (|d| >= 1e-9, degenerate_dir)
+    const bool sx = r.dx > 0.0, sy = r.dy > 0.0, sz = r.dz > 0.0;
+    r.sx = sx; r.sy = sy; r.sz = sz;
+    // relative error of ix: 2^-24 (d to f32) + 2^-23 (v_rcp_f32) < 2^-22.4
+    const float ix = __builtin_amdgcn_rcpf((float)r.dx), iy = __builtin_amdgcn_rcpf((float)r.dy), iz = __builtin_amdgcn_rcpf((float)r.dz);
     float cnx, cfx, cny, cfy, cnz, cfz;
     {
+        // slab distance = fma(plane, ix, c), c = -(o * ix) with the SAME ix: (plane - o) * ix, off by |plane - o| * |1/d| * 2^-22.4 <=
+        // big * |ix| * 2^-21.4; with the rounding of c (2^-24) and of the FMA (2^-23): 0.54 * 2^-20 * big * |ix|, inside the margin h
         const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
         const double delta = big * (1.0 / 1048576.0);
-        const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
-        const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+        const float hx = f32_above(delta * fabs((double)ix)), hy = f32_above(delta * fabs((double)iy)), hz = f32_above(delta * fabs((double)iz));
+        const float cx = (float)(-(orx * (double)ix)), cy = (float)(-(ory * (double)iy)), cz = (float)(-(orz * (double)iz));
         cnx = cx - hx; cfx = cx + hx; cny = cy - hy; cfy = cy + hy; cnz = cz - hz; cfz = cz + hz;
     }
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
@@ -1670,10 +1688,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         wide = !beam_ok || spread > RTX_COOP_WIDE * (float)sc.radius;
     }
     if (degen && !wide) retry_append(sq, light, (uint32_t)gid, sample, counters);   // (a wide group is left to k_shadow<MODE_ANY>, which appends)
-    // 1 / |d0| = |1 / d0|: the ray's own inverse direction (make_ray), no second division
-    const double inv0 = fabs(a0 == 0 ? r.ix : (a0 == 1 ? r.iy : r.iz));
-    grp_min_max(walk ? f32_below(d1 * inv0) : INF, walk ? f32_above(d1 * inv0) : -INF, &m1L, &m1H);
-    grp_min_max(walk ? f32_below(d2 * inv0) : INF, walk ? f32_above(d2 * inv0) : -INF, &m2L, &m2H);
+    // 1 / |d0| from the f32 inverse direction (relative error < 2^-22.4): the slopes are widened by 4e-7 of their size, which
+    // covers it, their rounding to f32 and the widening's own rounding
+    const double inv0 = (double)fabsf(a0 == 0 ? ix : (a0 == 1 ? iy : iz));
+    const float m1f = (float)(d1 * inv0), m2f = (float)(d2 * inv0);
+    const float m1w = fabsf(m1f) * 4.0e-7f, m2w = fabsf(m2f) * 4.0e-7f;
+    grp_min_max(walk ? m1f - m1w : INF, walk ? m1f + m1w : -INF, &m1L, &m1H);
+    grp_min_max(walk ? m2f - m2w : INF, walk ? m2f + m2w : -INF, &m2L, &m2H);
     const float umax = grp_max(walk ? f32_above((distance_to_light - tsh) * fabs(d0)) : 0.0f);
     {
         float big = fmaxf(fmaxf(fmaxf(fabsf(o0min), fabsf(o0max)), fmaxf(fabsf(o1min), fabsf(o1max))), fmaxf(fabsf(o2min), fabsf(o2max))) +

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <numeric>
 
 #include "rtx_bvh.h"
 
@@ -58,15 +59,24 @@ inline void reset(double *mn, double *mx) {
         mx[a] = -std::numeric_limits<double>::infinity();
     }
 }
+// a float <= x / >= x (x finite): the neighbour of the rounded value where rounding went the wrong way (std::nextafterf, inlined:
+// 1.7 M calls per 262 k prims)
+inline float f32_step(float f, bool up) {
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    if ((b & 0x7FFFFFFFu) == 0u) b = up ? 0x00000001u : 0x80000001u;   // +-0 -> the smallest denormal of the wanted sign
+    else if (((b >> 31) != 0u) == up) --b;                              // towards zero
+    else ++b;                                                           // away from zero
+    std::memcpy(&f, &b, 4);
+    return f;
+}
 inline float f32_down(double x) {
     float f = (float)x;
-    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
-    return f;
+    return (double)f > x ? f32_step(f, false) : f;
 }
 inline float f32_up(double x) {
     float f = (float)x;
-    if ((double)f < x) f = std::nextafterf(f, INFINITY);
-    return f;
+    return (double)f < x ? f32_step(f, true) : f;
 }
 
 constexpr int BINS = 16;
@@ -92,7 +102,8 @@ struct BinSet {
 // Large ranges (the top of the tree) are binned by all threads together; once a range is small its whole subtree is one task.
 struct Builder {
     const std::vector<RtxPrimBox> &prims;
-    std::vector<int> order;      // permutation of prim indices, partitioned in place
+    std::vector<int> order;      // permutation of prim indices, partitioned in place (stably: the tree does not depend on the thread count)
+    std::vector<int> scratch;    // copy of a range while all threads partition it
     std::vector<BNode> nodes;
     RtxPool &pool;
     unsigned n_threads;
@@ -133,9 +144,54 @@ struct Builder {
             }
         }
     }
+    // A short range (2 .. SWEEP_MAX prims): the exact SAH sweep over the prims sorted by centroid, per axis.  (Binning such a range
+    // cost a 4.8 KB BinSet cleared and 45 candidate planes evaluated per node, and most nodes of a tree built down to single prims
+    // are this short.)
+    static constexpr int SWEEP_MAX = 12;
+    int split_sweep(int begin, int end, BNode &nd) {
+        const int n = end - begin;
+        int idx[3][SWEEP_MAX];
+        double cen[3][SWEEP_MAX];
+        reset(nd.mn, nd.mx);
+        for (int i = 0; i < n; ++i) {
+            const RtxPrimBox &p = prims[(size_t)order[(size_t)(begin + i)]];
+            grow(nd.mn, nd.mx, p.mn, p.mx);
+            for (int a = 0; a < 3; ++a) {   // insertion sort by centroid (stable: equal centroids keep the list's order)
+                const double c = 0.5 * (p.mn[a] + p.mx[a]);
+                int j = i;
+                while (j > 0 && cen[a][j - 1] > c) { cen[a][j] = cen[a][j - 1]; idx[a][j] = idx[a][j - 1]; --j; }
+                cen[a][j] = c;
+                idx[a][j] = order[(size_t)(begin + i)];
+            }
+        }
+        int best_axis = -1, best_k = 0;
+        double best_cost = std::numeric_limits<double>::infinity();
+        for (int a = 0; a < 3; ++a) {
+            if (!(cen[a][n - 1] > cen[a][0])) continue;
+            double rarea[SWEEP_MAX];
+            double amn[3], amx[3];
+            reset(amn, amx);
+            for (int i = n - 1; i > 0; --i) {
+                const RtxPrimBox &p = prims[(size_t)idx[a][i]];
+                grow(amn, amx, p.mn, p.mx);
+                rarea[i] = area(amn, amx);
+            }
+            reset(amn, amx);
+            for (int k = 1; k < n; ++k) {   // left = the first k prims
+                const RtxPrimBox &p = prims[(size_t)idx[a][k - 1]];
+                grow(amn, amx, p.mn, p.mx);
+                const double cost = area(amn, amx) * k + rarea[k] * (n - k);
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_k = k; }
+            }
+        }
+        if (best_axis < 0) return begin + n / 2;   // all centroids coincide: split the list in half
+        for (int i = 0; i < n; ++i) order[(size_t)(begin + i)] = idx[best_axis][i];
+        return begin + best_k;
+    }
     // splits order[begin, end) (n >= 2) and returns the first index of the right part; nd receives the node's box
     int split(int begin, int end, BNode &nd, bool parallel) {
         const int n = end - begin;
+        if (n <= SWEEP_MAX) return split_sweep(begin, end, nd);
         double cmn[3], cmx[3];
         BinSet bs;
         bs.clear();
@@ -196,9 +252,33 @@ struct Builder {
         } else {
             const int a = best_axis;
             const double scale = (double)BINS / (cmx[a] - cmn[a]), c0 = cmn[a];
-            auto it = std::partition(order.begin() + begin, order.begin() + end,
-                                     [&](int pi) { return bin_of(prims[(size_t)pi], a, c0, scale) <= best_split; });
-            mid = (int)(it - order.begin());
+            auto is_left = [&](int pi) { return bin_of(prims[(size_t)pi], a, c0, scale) <= best_split; };
+            if (!parallel) {
+                mid = (int)(std::stable_partition(order.begin() + begin, order.begin() + end, is_left) - order.begin());
+            } else {   // the same stable partition by all threads: count per part, then scatter through a copy
+                const int parts = (int)n_threads * 4, len = (n + parts - 1) / parts;
+                std::vector<int> n_left((size_t)parts + 1, 0);
+                scratch.resize(order.size());
+                pool.run((size_t)parts, [&](size_t t) {
+                    int b0 = begin + (int)t * len, b1 = std::min(end, b0 + len), c = 0;
+                    for (int i = b0; i < b1; ++i) {
+                        scratch[(size_t)i] = order[(size_t)i];
+                        c += is_left(order[(size_t)i]) ? 1 : 0;
+                    }
+                    n_left[t + 1] = c;
+                });
+                for (int t = 0; t < parts; ++t) n_left[(size_t)t + 1] += n_left[(size_t)t];
+                mid = begin + n_left[(size_t)parts];
+                pool.run((size_t)parts, [&](size_t t) {
+                    int b0 = begin + (int)t * len, b1 = std::min(end, b0 + len);
+                    int l = begin + n_left[t], r = mid + (std::min(b0, end) - begin - n_left[t]);
+                    for (int i = b0; i < b1; ++i) {
+                        const int pi = scratch[(size_t)i];
+                        if (is_left(pi)) order[(size_t)l++] = pi;
+                        else order[(size_t)r++] = pi;
+                    }
+                });
+            }
             if (mid == begin || mid == end) mid = begin + n / 2;
         }
         return mid;
@@ -244,36 +324,43 @@ struct Builder {
         for (int a = 0; a < 3; ++a) { nd.mn[a] = p.mn[a]; nd.mx[a] = p.mx[a]; }
         nd.prim = order[(size_t)begin];
     }
-    // the subtree over order[begin, end) into `out` (out[0] = its root; children by local index), one thread
-    void build_local(std::vector<BNode> &out, int begin, int end) {
+    // the subtree over order[begin, end): its root is nodes[root], its other 2n - 2 nodes are nodes[base ...) in the order they are
+    // created (children after their parent), one thread
+    void build_local(int root, int base, int begin, int end) {
         struct Task { int node, begin, end; };
         std::vector<Task> stack;
-        out.emplace_back();
-        stack.push_back({0, begin, end});
+        int next = base;
+        stack.push_back({root, begin, end});
         while (!stack.empty()) {
             Task t = stack.back();
             stack.pop_back();
-            BNode nd;
+            BNode &nd = nodes[(size_t)t.node];
             if (t.end - t.begin == 1) {
                 leaf(t.begin, nd);
-                out[(size_t)t.node] = nd;
                 continue;
             }
             int mid = split(t.begin, t.end, nd, false);
             nd.sa = area(nd.mn, nd.mx);
-            nd.left = (int)out.size();
-            out.emplace_back();
-            nd.right = (int)out.size();
-            out.emplace_back();
-            out[(size_t)t.node] = nd;
+            nd.left = next++;
+            nd.right = next++;
             stack.push_back({nd.left, t.begin, mid});
             stack.push_back({nd.right, mid, t.end});
         }
-        collapse_costs(out, 0, out.size());
+        // collapse costs, children before parents: the subtree's own nodes backwards, then its root
+        collapse_costs(nodes, (size_t)base, (size_t)next);
+        collapse_costs(nodes, (size_t)root, (size_t)root + 1);
     }
     // builds the tree over all prims; returns the root's index in `nodes`
     int build() {
         struct Task { int node, begin, end; };
+        const bool timing = std::getenv("RTX_BUILD_TIMING") != nullptr;
+        auto tp = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "      %-24s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+            tp = now;
+        };
         std::vector<Task> top, subtree;
         nodes.clear();
         nodes.emplace_back();
@@ -296,21 +383,22 @@ struct Builder {
             top.push_back({nd.left, t.begin, mid});
             top.push_back({nd.right, mid, t.end});
         }
+        lap("top levels");
         const size_t n_top = nodes.size();
         std::vector<char> is_subtree_root(n_top, 0);
-        for (const Task &t : subtree) is_subtree_root[(size_t)t.node] = 1;
-        std::vector<std::vector<BNode>> local(subtree.size());
-        pool.run(subtree.size(), [&](size_t i) { build_local(local[i], subtree[i].begin, subtree[i].end); });
-        for (size_t i = 0; i < subtree.size(); ++i) {   // local node j > 0 becomes base + j - 1, local node 0 is nodes[subtree[i].node]
-            const int base = (int)nodes.size() - 1;
-            std::vector<BNode> &L = local[i];
-            for (BNode &b : L)
-                if (b.prim < 0) { b.left += base; b.right += base; }
-            nodes[(size_t)subtree[i].node] = L[0];
-            nodes.insert(nodes.end(), L.begin() + 1, L.end());
+        std::vector<int> base(subtree.size());
+        size_t total = n_top;
+        for (size_t i = 0; i < subtree.size(); ++i) {
+            is_subtree_root[(size_t)subtree[i].node] = 1;
+            base[i] = (int)total;
+            total += 2 * (size_t)(subtree[i].end - subtree[i].begin) - 2;
         }
+        nodes.resize(total);
+        pool.run(subtree.size(), [&](size_t i) { build_local(subtree[i].node, base[i], subtree[i].begin, subtree[i].end); });
+        lap("subtrees");
         for (size_t idx = n_top; idx-- > 0;)   // the top nodes (split with parallel passes), children before parents
             if (!is_subtree_root[idx]) collapse_costs(nodes, idx, idx + 1);
+        lap("top collapse costs");
         return 0;
     }
 };
@@ -320,18 +408,13 @@ struct Builder {
 void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
                         RtxWideStats *stats, RtxPool &pool) {
     out.clear();
-    auto add_node = [&]() {   // appends RTX_WIDE empty children, returns the node index
-        DWideChild c;
-        for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
-        c.ref = RTX_WREF_EMPTY;
-        c.first_node = 0;
-        uint32_t idx = (uint32_t)(out.size() / RTX_WIDE);
-        out.insert(out.end(), RTX_WIDE, c);
-        return idx;
-    };
+    DWideChild empty;
+    for (int a = 0; a < 3; ++a) { empty.lo[a] = INFINITY; empty.hi[a] = -INFINITY; }
+    empty.ref = RTX_WREF_EMPTY;
+    empty.first_node = 0;
     if (stats) *stats = RtxWideStats();
     if (prims.empty()) {
-        add_node();
+        out.assign(RTX_WIDE, empty);
         if (stats) { stats->nodes = 1; stats->depth = 1; }
         return;
     }
@@ -341,80 +424,87 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
     int broot = b.build();
     if (timing) std::fprintf(stderr, "    SAH binary tree %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const std::vector<BNode> &bn = b.nodes;
-    const bool greedy = std::getenv("RTX_BVH_GREEDY") != nullptr;
 
-    struct Task { uint32_t wide; int bnode; int depth; };
-    std::vector<Task> stack;
-    std::vector<int> kids;
-    kids.reserve(RTX_WIDE + 1);
-    out.reserve((prims.size() / 6 + 16) * RTX_WIDE);
-    stack.push_back({add_node(), broot, 1});
-    int max_depth = 0;
-    while (!stack.empty()) {
-        Task t = stack.back();
-        stack.pop_back();
-        kids.clear();
-        if (bn[(size_t)t.bnode].prim >= 0) kids.push_back(t.bnode);   // single-prim scene
-        else if (!greedy) {
-            // the children the collapse DP chose (Builder::collapse_costs): least expected number of node visits
+    // The wide nodes, level by level (breadth first), every level by all threads: pass 1 lists the children the collapse DP chose
+    // for each node of the level (Builder::collapse_costs: least expected number of node visits) and counts those that are nodes; a
+    // prefix sum gives every node the index of its first node-child (node-kind children have CONSECUTIVE indices in slot order, see
+    // DWideChild; the next level starts right behind this one); pass 2 writes the child records.
+    std::vector<int> level{broot}, next_level, kids;
+    std::vector<uint8_t> n_kids;
+    std::vector<uint32_t> first;
+    uint32_t level_first = 0;
+    int depth = 0;
+    int64_t prim_children = 0;
+    constexpr size_t CHUNK = 128;
+    while (!level.empty()) {
+        ++depth;
+        const size_t n = level.size(), n_chunks = (n + CHUNK - 1) / CHUNK;
+        kids.resize(n * RTX_WIDE);
+        n_kids.resize(n);
+        first.assign(n + 1, 0u);
+        pool.run(n_chunks, [&](size_t c) {
             struct Open { int node, slots; };
-            std::vector<Open> open;
-            const BNode &w = bn[(size_t)t.bnode];
-            open.push_back({w.right, RTX_WIDE - (int)w.own});
-            open.push_back({w.left, (int)w.own});
-            while (!open.empty()) {
-                Open o = open.back();
-                open.pop_back();
-                const BNode &k = bn[(size_t)o.node];
-                while (o.slots > 1 && k.prim < 0 && k.how[o.slots - 1] == 0) --o.slots;   // no better than with one slot fewer
-                if (k.prim >= 0 || o.slots == 1) { kids.push_back(o.node); continue; }      // a primitive, or a wide node of its own
-                const int kl = (int)k.how[o.slots - 1];
-                open.push_back({k.right, o.slots - kl});
-                open.push_back({k.left, kl});
+            Open open[2 * RTX_WIDE];
+            for (size_t i = c * CHUNK; i < std::min(n, (c + 1) * CHUNK); ++i) {
+                int *k_out = &kids[i * RTX_WIDE];
+                int nk = 0, nn = 0, top = 0;
+                const BNode &w = bn[(size_t)level[i]];
+                if (w.prim >= 0) {
+                    k_out[nk++] = level[i];   // single-prim scene
+                } else {
+                    open[top++] = {w.right, RTX_WIDE - (int)w.own};
+                    open[top++] = {w.left, (int)w.own};
+                }
+                while (top > 0) {
+                    Open o = open[--top];
+                    const BNode &k = bn[(size_t)o.node];
+                    while (o.slots > 1 && k.prim < 0 && k.how[o.slots - 1] == 0) --o.slots;   // no better than with one slot fewer
+                    if (k.prim >= 0 || o.slots == 1) {                                          // a primitive, or a wide node of its own
+                        k_out[nk++] = o.node;
+                        nn += k.prim < 0 ? 1 : 0;
+                        continue;
+                    }
+                    const int kl = (int)k.how[o.slots - 1];
+                    open[top++] = {k.right, o.slots - kl};
+                    open[top++] = {k.left, kl};
+                }
+                n_kids[i] = (uint8_t)nk;
+                first[i + 1] = (uint32_t)nn;
             }
-        } else { kids.push_back(bn[(size_t)t.bnode].left); kids.push_back(bn[(size_t)t.bnode].right); }
-        // (RTX_BVH_GREEDY: up to RTX_WIDE children by opening the largest internal child first)
-        for (; greedy;) {
-            if ((int)kids.size() >= RTX_WIDE) break;
-            int pick = -1;
-            double pa = -1.0;
-            for (size_t i = 0; i < kids.size(); ++i) {
-                const BNode &k = bn[(size_t)kids[i]];
-                if (k.prim >= 0) continue;
-                if (k.sa > pa) { pa = k.sa; pick = (int)i; }
+        });
+        for (size_t i = 0; i < n; ++i) first[i + 1] += first[i];
+        const uint32_t next_first = level_first + (uint32_t)n, n_next = first[n];
+        out.resize((size_t)(next_first + n_next) * RTX_WIDE, empty);
+        next_level.resize(n_next);
+        prim_children += (int64_t)std::accumulate(n_kids.begin(), n_kids.end(), (int64_t)0) - (int64_t)n_next;
+        pool.run(n_chunks, [&](size_t c) {
+            for (size_t i = c * CHUNK; i < std::min(n, (c + 1) * CHUNK); ++i) {
+                DWideChild *rec = &out[((size_t)level_first + i) * RTX_WIDE];
+                uint32_t nn = first[i];
+                for (int j = 0; j < (int)n_kids[i]; ++j) {
+                    const int kid = kids[i * RTX_WIDE + (size_t)j];
+                    const BNode &k = bn[(size_t)kid];
+                    DWideChild &w = rec[j];
+                    for (int a = 0; a < 3; ++a) {
+                        w.lo[a] = f32_down(k.mn[a] - centre[a]);
+                        w.hi[a] = f32_up(k.mx[a] - centre[a]);
+                    }
+                    if (k.prim >= 0) {
+                        w.ref = prims[(size_t)k.prim].ref;
+                    } else {
+                        w.ref = RTX_WREF_NODE | (next_first + nn);
+                        next_level[nn++] = kid;
+                    }
+                }
+                for (int j = 0; j < RTX_WIDE; ++j) rec[j].first_node = first[i + 1] > first[i] ? next_first + first[i] : 0u;
             }
-            if (pick < 0) break;
-            int k = kids[(size_t)pick];
-            kids[(size_t)pick] = bn[(size_t)k].left;
-            kids.push_back(bn[(size_t)k].right);
-        }
-        max_depth = std::max(max_depth, t.depth);
-        // node-kind children get CONSECUTIVE node indices in slot order (see DWideChild)
-        uint32_t first_node = 0;
-        bool have_first = false;
-        for (size_t i = 0; i < kids.size(); ++i) {
-            const BNode &k = bn[(size_t)kids[i]];
-            uint32_t ref;
-            if (k.prim >= 0) {
-                ref = prims[(size_t)k.prim].ref;
-                if (stats) ++stats->prim_children;
-            } else {
-                uint32_t idx = add_node();
-                if (!have_first) { first_node = idx; have_first = true; }
-                ref = RTX_WREF_NODE | idx;
-                stack.push_back({idx, kids[i], t.depth + 1});
-            }
-            DWideChild &w = out[(size_t)t.wide * RTX_WIDE + i];
-            for (int a = 0; a < 3; ++a) {
-                w.lo[a] = f32_down(k.mn[a] - centre[a]);
-                w.hi[a] = f32_up(k.mx[a] - centre[a]);
-            }
-            w.ref = ref;
-        }
-        for (int i = 0; i < RTX_WIDE; ++i) out[(size_t)t.wide * RTX_WIDE + (size_t)i].first_node = first_node;
+        });
+        level_first = next_first;
+        level.swap(next_level);
     }
     if (stats) {
         stats->nodes = (int64_t)(out.size() / RTX_WIDE);
-        stats->depth = max_depth;
+        stats->depth = depth;
+        stats->prim_children = prim_children;
     }
 }

@@ -178,11 +178,15 @@ typedef struct rtx_options {
 } rtx_options;
 
 enum {
+    RTX_FLAG_OCTREE_WALK = 8,    /* the per-lane closest-hit and any-hit walks run over the reference's octree (conservative f32
+                                    twins of its nodes and leaf entries) instead of the 4-wide SAH hierarchy built beside it (A/B
+                                    measurements and tests: both reach a superset of the prims a ray truly hits and decide each
+                                    with the same exact f64 tests, so the results are the same but for exact-t ties) */
     RTX_FLAG_SERIAL = 4,         /* everything on the caller's stream, one launch after the other: by default the
                                     shadow launches of a wavefront step run on a stream of the library's own and
                                     overlap the next step's closest-hit launch (A/B measurements, clean per-kernel
                                     timings; the image does not depend on it beyond the order of f64 atomic adds) */
-    RTX_FLAG_NO_COOP = 2,        /* shadow feelers walk the octree one ray per lane instead of the
+    RTX_FLAG_NO_COOP = 2,        /* shadow feelers walk one ray per lane instead of the
                                     cooperative 16-lane box-list traversal (A/B measurements; the
                                     cooperative kernel is used for 4, 8 or a multiple of 16 tries per
                                     hit point in scenes without transmissive materials) */

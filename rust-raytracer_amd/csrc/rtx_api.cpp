@@ -1187,12 +1187,18 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         pboxes[(size_t)i].ref = r >= 0 ? (RTX_WREF_TRI | (uint32_t)r) : (RTX_WREF_SPHERE | (uint32_t)(~r));
     }
     std::vector<DWideChild> wide;
+    std::vector<DNode4> bvh4;
     RtxWideStats wstats;
-    rtx_build_wide_bvh(pboxes, centre, wide, &wstats, pool);
+    rtx_build_hierarchies(pboxes, centre, wide, bvh4, &wstats, pool);
     // k_shadow_coop's level stack (24 levels), queue entry bits, 23-bit prim index of a waiting pair
     const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 26) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
-    lap("wide box lists (SAH)");
+    // traverse_bvh's stack entries: node index | quantised entry distance (at least 6 bits of it)
+    uint32_t bvh4_bits = 1;
+    while ((1ll << bvh4_bits) < wstats.nodes4) ++bvh4_bits;
+    const bool bvh4_ok = bvh4_bits <= 26 && std::getenv("RTX_NO_BVH4") == nullptr;
+    lap("hierarchies (SAH)");
     up.submit(wide, &ds.wide);
+    up.submit(bvh4, &ds.bvh4);
     if ((st = up.finish(s.get()))) return cleanup(st);
     DNode32 *d_nodes32 = nullptr;
     DEntry32 *d_entries32 = nullptr;
@@ -1208,7 +1214,10 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipGetLastError());
     lap("f32 twins (device)");
-    if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane octree walk
+    if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane walk
+    if (!bvh4_ok) ds.bvh4 = nullptr;   // the per-lane walks fall back to the octree
+    ds.bvh4_node_bits = bvh4_bits;
+    ds.pad0_ = 0;
     s->n_materials = d->n_materials;
     s->n_textures = d->n_textures;
     ds.n_planes = (int32_t)planes.size();

@@ -35,13 +35,25 @@ struct BNode {
     int left = -1, right = -1;   // binary children, or
     int prim = -1;               // leaf: index into the prim list
     double sa = 0.0;             // surface area of the box (the collapse picks by it)
-    // collapse DP (see collapse_costs): cost[i-1] = least expected number of wide-node visits below this node when its subtree
-    // is handed i child slots of a wide node; how[i-1] = 0: as with i - 1 slots, k > 0: left child gets k slots, right i - k;
-    // how[0] is unused (one slot: the node becomes a wide node of its own, or is a primitive)
-    // own = the split of the RTX_WIDE slots between the two children when this node is a wide node itself
-    float cost[RTX_WIDE];
-    uint8_t how[RTX_WIDE], own;
+    // collapse DP (see collapse_costs), once per width: cost[i-1] = least expected number of wide-node visits below this node when its
+    // subtree is handed i child slots of a wide node; how[i-1] = 0: as with i - 1 slots, k > 0: left child gets k slots, right i - k;
+    // how[0] is unused (one slot: the node becomes a wide node of its own, or is a primitive); own = the split of the W slots
+    // between the two children when this node is a wide node itself
+    template <int W>
+    struct Collapse {
+        float cost[W];
+        uint8_t how[W], own;
+    };
+    Collapse<RTX_WIDE> c16;    // the 16-wide box lists of the cooperative shadow walk
+    Collapse<RTX_BVH4> c4;     // the 4-wide nodes of the per-lane walks
+    template <int W> Collapse<W> &collapse();
+    template <int W> const Collapse<W> &collapse() const;
 };
+template <> inline BNode::Collapse<RTX_WIDE> &BNode::collapse<RTX_WIDE>() { return c16; }
+template <> inline BNode::Collapse<RTX_BVH4> &BNode::collapse<RTX_BVH4>() { return c4; }
+template <> inline const BNode::Collapse<RTX_WIDE> &BNode::collapse<RTX_WIDE>() const { return c16; }
+template <> inline const BNode::Collapse<RTX_BVH4> &BNode::collapse<RTX_BVH4>() const { return c4; }
+
 
 inline double area(const double *mn, const double *mx) {
     double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
@@ -287,36 +299,40 @@ struct Builder {
     // wide node costs the same whatever it holds (16 lanes test its 16 slots at once), and a primitive is queued iff the beam touches
     // its own box, whatever the structure above it; so the collapse minimises the expected number of NODE VISITS, sum of area(node)
     // over wide nodes.  v[] must be in an order where children come after their parents (true for every vector built here).
+    template <int W>
+    static void collapse_node(BNode &n, const BNode &l, const BNode &r) {
+        BNode::Collapse<W> &c = n.collapse<W>();
+        const BNode::Collapse<W> &lc = l.collapse<W>(), &rc = r.collapse<W>();
+        float d[W + 1];
+        uint8_t dk[W + 1];
+        for (int j = 2; j <= W; ++j) {
+            float best = std::numeric_limits<float>::infinity();
+            int bk = 1;
+            for (int k = 1; k < j; ++k) {
+                float cc = lc.cost[k - 1] + rc.cost[j - k - 1];
+                if (cc < best) { best = cc; bk = k; }
+            }
+            d[j] = best;
+            dk[j] = (uint8_t)bk;
+        }
+        c.cost[0] = (float)n.sa + d[W];
+        c.how[0] = 0;
+        c.own = dk[W];
+        for (int i = 2; i <= W; ++i) {
+            if (d[i] < c.cost[i - 2]) { c.cost[i - 1] = d[i]; c.how[i - 1] = dk[i]; }
+            else { c.cost[i - 1] = c.cost[i - 2]; c.how[i - 1] = 0; }
+        }
+    }
     static void collapse_costs(std::vector<BNode> &v, size_t first, size_t last) {
         for (size_t idx = last; idx-- > first;) {
             BNode &n = v[idx];
             if (n.prim >= 0) {
-                for (int i = 0; i < RTX_WIDE; ++i) { n.cost[i] = 0.0f; n.how[i] = 0; }
-                n.own = 0;
+                std::memset(&n.c16, 0, sizeof n.c16);
+                std::memset(&n.c4, 0, sizeof n.c4);
                 continue;
             }
-            const BNode &l = v[(size_t)n.left], &r = v[(size_t)n.right];
-            float d[RTX_WIDE + 1];
-            uint8_t dk[RTX_WIDE + 1];
-            for (int j = 2; j <= RTX_WIDE; ++j) {
-                float best = std::numeric_limits<float>::infinity();
-                int bk = 1;
-                for (int k = 1; k < j; ++k) {
-                    float c = l.cost[k - 1] + r.cost[j - k - 1];
-                    if (c < best) { best = c; bk = k; }
-                }
-                d[j] = best;
-                dk[j] = (uint8_t)bk;
-            }
-            static const double infl = std::getenv("RTX_BVH_INFLATE") ? std::atof(std::getenv("RTX_BVH_INFLATE")) : 0.0;
-            const double ex = n.mx[0] - n.mn[0] + infl, ey = n.mx[1] - n.mn[1] + infl, ez = n.mx[2] - n.mn[2] + infl;
-            n.cost[0] = (float)(2.0 * (ex * ey + ey * ez + ez * ex)) + d[RTX_WIDE];
-            n.how[0] = 0;
-            n.own = dk[RTX_WIDE];
-            for (int i = 2; i <= RTX_WIDE; ++i) {
-                if (d[i] < n.cost[i - 2]) { n.cost[i - 1] = d[i]; n.how[i - 1] = dk[i]; }
-                else { n.cost[i - 1] = n.cost[i - 2]; n.how[i - 1] = 0; }
-            }
+            collapse_node<RTX_WIDE>(n, v[(size_t)n.left], v[(size_t)n.right]);
+            collapse_node<RTX_BVH4>(n, v[(size_t)n.left], v[(size_t)n.right]);
         }
     }
     void leaf(int begin, BNode &nd) const {
@@ -403,68 +419,52 @@ struct Builder {
     }
 };
 
-} // namespace
-
-void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
-                        RtxWideStats *stats, RtxPool &pool) {
-    out.clear();
-    DWideChild empty;
-    for (int a = 0; a < 3; ++a) { empty.lo[a] = INFINITY; empty.hi[a] = -INFINITY; }
-    empty.ref = RTX_WREF_EMPTY;
-    empty.first_node = 0;
-    if (stats) *stats = RtxWideStats();
-    if (prims.empty()) {
-        out.assign(RTX_WIDE, empty);
-        if (stats) { stats->nodes = 1; stats->depth = 1; }
-        return;
-    }
-    const bool timing = std::getenv("RTX_BUILD_TIMING") != nullptr;
-    auto t0 = std::chrono::steady_clock::now();
-    Builder b(prims, pool);
-    int broot = b.build();
-    if (timing) std::fprintf(stderr, "    SAH binary tree %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    const std::vector<BNode> &bn = b.nodes;
-
-    // The wide nodes, level by level (breadth first), every level by all threads: pass 1 lists the children the collapse DP chose
-    // for each node of the level (Builder::collapse_costs: least expected number of node visits) and counts those that are nodes; a
-    // prefix sum gives every node the index of its first node-child (node-kind children have CONSECUTIVE indices in slot order, see
-    // DWideChild; the next level starts right behind this one); pass 2 writes the child records.
-    std::vector<int> level{broot}, next_level, kids;
+// The W-wide nodes the collapse DP chose, level by level (breadth first), every level by all threads: pass 1 lists the children of
+// each node of the level (Builder::collapse_costs: least expected number of node visits) and counts those that are nodes; a prefix
+// sum gives every node the index of its first node-child (node-kind children get CONSECUTIVE indices in slot order; the next level
+// starts right behind this one); pass 2 hands each node to `write(node index, kids, n kids, index of its first node-child)`.
+// `grow(n)` is called before a level's nodes are written: the output must then hold n nodes.
+template <int W, class Grow, class Write>
+void emit_levels(const std::vector<BNode> &bn, int root, RtxPool &pool, Grow grow, Write write, int *depth_out, int64_t *prim_children_out) {
+    std::vector<int> level{root}, next_level, kids;
     std::vector<uint8_t> n_kids;
     std::vector<uint32_t> first;
     uint32_t level_first = 0;
     int depth = 0;
     int64_t prim_children = 0;
     constexpr size_t CHUNK = 128;
+    grow((size_t)1);
     while (!level.empty()) {
         ++depth;
         const size_t n = level.size(), n_chunks = (n + CHUNK - 1) / CHUNK;
-        kids.resize(n * RTX_WIDE);
+        kids.resize(n * W);
         n_kids.resize(n);
         first.assign(n + 1, 0u);
         pool.run(n_chunks, [&](size_t c) {
             struct Open { int node, slots; };
-            Open open[2 * RTX_WIDE];
+            Open open[2 * W];
             for (size_t i = c * CHUNK; i < std::min(n, (c + 1) * CHUNK); ++i) {
-                int *k_out = &kids[i * RTX_WIDE];
+                int *k_out = &kids[i * W];
                 int nk = 0, nn = 0, top = 0;
                 const BNode &w = bn[(size_t)level[i]];
                 if (w.prim >= 0) {
                     k_out[nk++] = level[i];   // single-prim scene
                 } else {
-                    open[top++] = {w.right, RTX_WIDE - (int)w.own};
-                    open[top++] = {w.left, (int)w.own};
+                    const int own = (int)w.collapse<W>().own;
+                    open[top++] = {w.right, W - own};
+                    open[top++] = {w.left, own};
                 }
                 while (top > 0) {
                     Open o = open[--top];
                     const BNode &k = bn[(size_t)o.node];
-                    while (o.slots > 1 && k.prim < 0 && k.how[o.slots - 1] == 0) --o.slots;   // no better than with one slot fewer
-                    if (k.prim >= 0 || o.slots == 1) {                                          // a primitive, or a wide node of its own
+                    const uint8_t *how = k.collapse<W>().how;
+                    while (o.slots > 1 && k.prim < 0 && how[o.slots - 1] == 0) --o.slots;   // no better than with one slot fewer
+                    if (k.prim >= 0 || o.slots == 1) {                                        // a primitive, or a wide node of its own
                         k_out[nk++] = o.node;
                         nn += k.prim < 0 ? 1 : 0;
                         continue;
                     }
-                    const int kl = (int)k.how[o.slots - 1];
+                    const int kl = (int)how[o.slots - 1];
                     open[top++] = {k.right, o.slots - kl};
                     open[top++] = {k.left, kl};
                 }
@@ -474,37 +474,92 @@ void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centr
         });
         for (size_t i = 0; i < n; ++i) first[i + 1] += first[i];
         const uint32_t next_first = level_first + (uint32_t)n, n_next = first[n];
-        out.resize((size_t)(next_first + n_next) * RTX_WIDE, empty);
+        grow((size_t)next_first + n_next);
         next_level.resize(n_next);
         prim_children += (int64_t)std::accumulate(n_kids.begin(), n_kids.end(), (int64_t)0) - (int64_t)n_next;
         pool.run(n_chunks, [&](size_t c) {
             for (size_t i = c * CHUNK; i < std::min(n, (c + 1) * CHUNK); ++i) {
-                DWideChild *rec = &out[((size_t)level_first + i) * RTX_WIDE];
+                const int *k_in = &kids[i * W];
                 uint32_t nn = first[i];
-                for (int j = 0; j < (int)n_kids[i]; ++j) {
-                    const int kid = kids[i * RTX_WIDE + (size_t)j];
-                    const BNode &k = bn[(size_t)kid];
-                    DWideChild &w = rec[j];
-                    for (int a = 0; a < 3; ++a) {
-                        w.lo[a] = f32_down(k.mn[a] - centre[a]);
-                        w.hi[a] = f32_up(k.mx[a] - centre[a]);
-                    }
-                    if (k.prim >= 0) {
-                        w.ref = prims[(size_t)k.prim].ref;
-                    } else {
-                        w.ref = RTX_WREF_NODE | (next_first + nn);
-                        next_level[nn++] = kid;
-                    }
-                }
-                for (int j = 0; j < RTX_WIDE; ++j) rec[j].first_node = first[i + 1] > first[i] ? next_first + first[i] : 0u;
+                for (int j = 0; j < (int)n_kids[i]; ++j)
+                    if (bn[(size_t)k_in[j]].prim < 0) next_level[nn++] = k_in[j];
+                write(level_first + (uint32_t)i, k_in, (int)n_kids[i], next_first + first[i]);
             }
         });
         level_first = next_first;
         level.swap(next_level);
     }
+    *depth_out = depth;
+    *prim_children_out = prim_children;
+}
+
+} // namespace
+
+void rtx_build_hierarchies(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
+                           std::vector<DNode4> &out4, RtxWideStats *stats, RtxPool &pool) {
+    out.clear();
+    out4.clear();
+    DWideChild empty;
+    for (int a = 0; a < 3; ++a) { empty.lo[a] = INFINITY; empty.hi[a] = -INFINITY; }
+    empty.ref = RTX_WREF_EMPTY;
+    empty.first_node = 0;
+    DNode4 empty4;
+    for (int a = 0; a < 3; ++a)
+        for (int j = 0; j < RTX_BVH4; ++j) { empty4.lo[a][j] = INFINITY; empty4.hi[a][j] = -INFINITY; }
+    for (int j = 0; j < RTX_BVH4; ++j) empty4.ref[j] = RTX_WREF_EMPTY;
+    if (stats) *stats = RtxWideStats();
+    if (prims.empty()) {
+        out.assign(RTX_WIDE, empty);
+        out4.assign(1, empty4);
+        if (stats) { stats->nodes = 1; stats->depth = 1; stats->nodes4 = 1; stats->depth4 = 1; }
+        return;
+    }
+    const bool timing = std::getenv("RTX_BUILD_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    Builder b(prims, pool);
+    int broot = b.build();
+    if (timing) std::fprintf(stderr, "    SAH binary tree %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    const std::vector<BNode> &bn = b.nodes;
+
+    int depth = 0, depth4 = 0;
+    int64_t prim_children = 0, prim_children4 = 0;
+    emit_levels<RTX_WIDE>(
+        bn, broot, pool, [&](size_t n_nodes) { out.resize(n_nodes * RTX_WIDE, empty); },
+        [&](uint32_t node, const int *kids, int nk, uint32_t first_node) {
+            DWideChild *rec = &out[(size_t)node * RTX_WIDE];
+            uint32_t nn = first_node;
+            for (int j = 0; j < nk; ++j) {
+                const BNode &k = bn[(size_t)kids[j]];
+                DWideChild &w = rec[j];
+                for (int a = 0; a < 3; ++a) {
+                    w.lo[a] = f32_down(k.mn[a] - centre[a]);
+                    w.hi[a] = f32_up(k.mx[a] - centre[a]);
+                }
+                w.ref = k.prim >= 0 ? prims[(size_t)k.prim].ref : (RTX_WREF_NODE | nn++);
+            }
+            for (int j = 0; j < RTX_WIDE; ++j) rec[j].first_node = nn > first_node ? first_node : 0u;
+        },
+        &depth, &prim_children);
+    emit_levels<RTX_BVH4>(
+        bn, broot, pool, [&](size_t n_nodes) { out4.resize(n_nodes, empty4); },
+        [&](uint32_t node, const int *kids, int nk, uint32_t first_node) {
+            DNode4 &rec = out4[(size_t)node];
+            uint32_t nn = first_node;
+            for (int j = 0; j < nk; ++j) {
+                const BNode &k = bn[(size_t)kids[j]];
+                for (int a = 0; a < 3; ++a) {
+                    rec.lo[a][j] = f32_down(k.mn[a] - centre[a]);
+                    rec.hi[a][j] = f32_up(k.mx[a] - centre[a]);
+                }
+                rec.ref[j] = k.prim >= 0 ? prims[(size_t)k.prim].ref : (RTX_WREF_NODE | nn++);
+            }
+        },
+        &depth4, &prim_children4);
     if (stats) {
         stats->nodes = (int64_t)(out.size() / RTX_WIDE);
         stats->depth = depth;
         stats->prim_children = prim_children;
+        stats->nodes4 = (int64_t)out4.size();
+        stats->depth4 = depth4;
     }
 }

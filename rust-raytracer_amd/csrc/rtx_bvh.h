@@ -84,9 +84,11 @@ struct RtxPrimBox {
     uint32_t ref;        // RTX_WREF_TRI | triangle index  or  RTX_WREF_SPHERE | sphere index
 };
 struct RtxWideStats {
-    int64_t nodes = 0, prim_children = 0;
-    int depth = 0;
+    int64_t nodes = 0, prim_children = 0, nodes4 = 0;
+    int depth = 0, depth4 = 0;
 };
-// Boxes are stored relative to `centre`, rounded outward to f32.  pool: worker threads of the SAH build (the tree does not depend on their number).
-void rtx_build_wide_bvh(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
-                        RtxWideStats *stats, RtxPool &pool);
+// One binned-SAH binary tree over the prims, cut twice: into 16-wide box lists (`out`, the cooperative shadow walk) and into 4-wide
+// nodes (`out4`, the per-lane closest-hit and any-hit walks).  Boxes are stored relative to `centre`, rounded outward to f32.
+// pool: worker threads of the build (the trees do not depend on their number).
+void rtx_build_hierarchies(const std::vector<RtxPrimBox> &prims, const double centre[3], std::vector<DWideChild> &out,
+                           std::vector<DNode4> &out4, RtxWideStats *stats, RtxPool &pool);

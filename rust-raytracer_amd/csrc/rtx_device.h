@@ -63,6 +63,17 @@ struct alignas(32) DWideChild {
     uint32_t first_node;   // same value in all RTX_WIDE children of a node
 };
 
+// A node of the 4-wide hierarchy walked per lane (closest hit, any-hit feelers of scenes without transmissive materials): the same
+// binary SAH tree as the box lists, cut into 4-wide nodes; SoA so that one 16-byte load fetches a bound of all four children, and
+// a lane picks the near / far planes of its ray's direction signs by ADDRESS (lo or hi row), not by per-component selects.
+// 112 B.  ref: RTX_WREF_* kind | index (a node's children that are nodes need not be consecutive here).
+#define RTX_BVH4 4
+struct alignas(16) DNode4 {
+    float lo[3][RTX_BVH4];
+    float hi[3][RTX_BVH4];
+    uint32_t ref[RTX_BVH4];
+};
+
 // Intersection record of a triangle: 3 vertices (triangle.rs:90) + ids, 80 B, 16-B aligned.
 struct alignas(16) DTri {
     double v[9];
@@ -99,6 +110,9 @@ struct DScene {
     const DEntry32 *entries32;  // same order as leaf_refs
     const int32_t *leaf_refs;   // >= 0: triangle index, < 0: ~sphere index
     const DWideChild *wide;     // 16-wide hierarchy over the finite prims: node n = wide[16 n .. 16 n + 15], node 0 = root
+    const DNode4 *bvh4;         // 4-wide hierarchy over the same prims, node 0 = root; NULL: the per-lane walks use the octree
+    uint32_t bvh4_node_bits;    // bits of a stack entry that hold the node index (the rest: quantised entry distance)
+    uint32_t pad0_;
     const DTri *tris;
     const DTriShade *tri_shade;
     const DSphere *spheres;
@@ -164,7 +178,7 @@ struct DShadowQ {
 // reference's walk (k_shadow<MODE_PRODUCT>), which is valid for every feeler of every scene.  Set for the re-render of a frame
 // whose retry list overflowed (more degenerate feelers in one launch than the list holds).
 #define RTX_FLAG_INTERNAL_EXACT_SHADOWS 0x80000000u
-#define RTX_FLAG_PUBLIC_MASK 0x7u
+#define RTX_FLAG_PUBLIC_MASK 0xFu
 
 struct DCounters {
     uint32_t pool_tail;

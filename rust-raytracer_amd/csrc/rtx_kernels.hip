@@ -247,7 +247,8 @@ DEV bool plane_hit(const DPlane &pl, const Ray &r, double t_min, double t_max, d
 // MODE_PRODUCT_FAST: the same multiset as MODE_PRODUCT, boxes classified in f32 (traverse_ww<WW_PRODUCT>).
 // MODE_PRODUCT:      shadow feeler with transmissive materials: every candidate of the
 //                    multiset, duplicates included (renderer.rs:209-217), order-free product.
-enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4 };
+// MODE_CLOSEST_BVH / MODE_ANY_BVH: MODE_CLOSEST / MODE_ANY over the 4-wide hierarchy instead of the octree (traverse_bvh).
+enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4, MODE_CLOSEST_BVH = 5, MODE_ANY_BVH = 6 };
 
 struct Hit {
     double t;
@@ -807,6 +808,196 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 }
 
+// Closest hit / any hit over the 4-WIDE HIERARCHY (DNode4), one ray per lane: the walk of k_closest, k_nearest and k_shadow<MODE_ANY>
+// in scenes whose hierarchy was built (DScene.bvh4).  Both searches depend only on the SET of primitives that truly intersect the
+// ray, each decided by the reference's exact f64 entry-bbox and primitive tests (octree.rs:170, ray.rs:50-55 / renderer.rs:212); the
+// walk only has to reach a superset of them, and any conservative structure over the finite prims does (the
+// argument the box lists of the cooperative shadow walk rest on).  The reference's octree lists a prim in every leaf its box
+// overlaps (5 entries per triangle in the sponza stand-in) and a lane's walk over it fetched 26 nodes and 33 leaf entries per ray;
+// the SAH tree holds every prim once: 14 node visits per ray, no mailbox.
+//   Same three phases as traverse_ww (bounded descent, candidates PARKED in LDS, wave-wide flushes with the exact tests), same f32
+// frame and margins.  A visit fetches the near and far planes of the four children with six 16-byte loads whose row (lo or hi) the
+// lane picks by its direction signs, tests the four boxes, parks the prim children that are hit and continues with the nearest
+// node child; the other node children go onto the lane's stack in LDS together with their entry distance, quantised DOWNWARDS into
+// the bits the node index leaves free, so that a pop can drop what lies behind the best hit by then.  A full stack (never seen:
+// 16 entries, 3.4 needed on average) sets *overflow and ends the walk: the caller hands the ray to the all-f64 walk.
+#define RTX_BVH_STACK 16
+#define RTX_BVH_CAND 8        // candidates a lane can park; a visit needs room for 4
+#ifndef RTX_BVH_STEPS
+#define RTX_BVH_STEPS 3       // node visits per lane and round before the wave looks at the parked candidates
+#endif
+#ifndef RTX_BVH_FLUSH
+#define RTX_BVH_FLUSH 24
+#endif
+template <int WW>
+DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_stack, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
+                      bool *overflow) {
+    static_assert(WW == WW_CLOSEST || WW == WW_ANY, "the shadow product needs the reference's octree (traverse_ww<WW_PRODUCT>)");
+    constexpr bool ANY = WW == WW_ANY;
+    uint32_t *stk = s_stack + threadIdx.x;   // stride RTX_BLOCK
+    uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
+    double best_t = ANY ? t_hi : inf();      // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
+    int best_ref = REF_NONE;
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
+
+    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh
+    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
+    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+    const double delta = big * (1.0 / 1048576.0);
+    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
+    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
+    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
+    float bf = f32_above(best_t - tsh);
+    // rows of a DNode4 in 16-byte units: lo.x lo.y lo.z hi.x hi.y hi.z ref
+    const uint32_t onx = r.sx ? 0u : 3u, ofx = r.sx ? 3u : 0u, ony = r.sy ? 1u : 4u, ofy = r.sy ? 4u : 1u, onz = r.sz ? 2u : 5u, ofz = r.sz ? 5u : 2u;
+    // stack entry = node index | quantised entry distance << node_bits; the distance is rounded DOWN (a pop never drops a node that
+    // could still hold the closest hit); every entry distance lies in [0, 4 * big]
+    const uint32_t nbits = sc.bvh4_node_bits, nmask = (1u << nbits) - 1u;
+    const float qmax = (float)((1u << (32u - nbits)) - 1u);
+    const float qscale = qmax / (4.0f * (float)big) * 0.999999f;
+    const float qinv = 4.0f * (float)big / qmax * 0.999999f;
+
+    uint32_t sp = 0u, cnt = 0u, cur = 0u;
+    bool running = active && !re.miss;   // a ray that misses the scene's cube has no finite candidate
+    bool have_cur = running;             // the root (octree.rs:149,177 never tests the root's box; neither does this walk)
+    bool ovf = false;
+    const float INF = __int_as_float(0x7F800000);
+
+    for (;;) {
+        if (!__any(running || cnt > 0u)) break;
+        for (int step = 0; step < RTX_BVH_STEPS && running && cnt <= RTX_BVH_CAND - RTX_BVH4; ++step) {
+            if (!have_cur) {
+                if (sp == 0u) { running = false; break; }
+                --sp;
+                const uint32_t e = stk[sp * RTX_BLOCK];
+                if (!ANY && (float)(e >> nbits) * qinv > bf) continue;   // it starts behind the best hit
+                cur = e & nmask;
+            }
+            have_cur = false;
+            WORK(++w_nodes;)
+            const float4 *nq = reinterpret_cast<const float4 *>(sc.bvh4 + cur);
+            const float4 pnx = nq[onx], pny = nq[ony], pnz = nq[onz], pfx = nq[ofx], pfy = nq[ofy], pfz = nq[ofz];
+            const uint4 rf = reinterpret_cast<const uint4 *>(nq)[6];
+            const float nxs[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, nys[4] = {pny.x, pny.y, pny.z, pny.w}, nzs[4] = {pnz.x, pnz.y, pnz.z, pnz.w};
+            const float fxs[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, fys[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, fzs[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
+            const uint32_t refs[4] = {rf.x, rf.y, rf.z, rf.w};
+            float key[4];   // entry distance of a node child that is hit, else +inf
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // (an empty slot's box is (+inf, -inf): lo > hi or NaN, never hit)
+                const float lo = fmaxf(fmaxf(fmaxf(fmaf(nxs[c], ix, cnx), 0.0f), fmaf(nys[c], iy, cny)), fmaf(nzs[c], iz, cnz));
+                const float hi = fminf(fminf(fminf(fmaf(fxs[c], ix, cfx), bf), fmaf(fys[c], iy, cfy)), fmaf(fzs[c], iz, cfz));
+                const bool hit_c = lo <= hi;
+                const uint32_t kind = refs[c] & RTX_WREF_KIND;
+                key[c] = (hit_c && kind == RTX_WREF_NODE) ? lo : INF;
+                if (hit_c && (kind == RTX_WREF_TRI || kind == RTX_WREF_SPHERE)) {
+                    WORK(++w_entries;)
+                    // the box shrunk by delta instead of widened: a ray through it passes the exact f64 entry test (octree.rs:170)
+                    // with a margin far above f64 rounding, so that test can be skipped
+                    bool surely_in = false;
+                    if (finite_dir) {
+                        const float li = fmaxf(fmaxf(fmaf(nxs[c], ix, cfx), fmaf(nys[c], iy, cfy)), fmaf(nzs[c], iz, cfz));
+                        const float hi2 = fminf(fminf(fmaf(fxs[c], ix, cnx), fmaf(fys[c], iy, cny)), fmaf(fzs[c], iz, cnz));
+                        surely_in = li <= hi2 && hi2 > 0.0f;
+                    }
+                    const uint32_t idx = refs[c] & RTX_WREF_INDEX;
+                    const int ref = kind == RTX_WREF_TRI ? (int)idx : ~(int)idx;
+                    cand[cnt * RTX_BLOCK] = ((uint32_t)ref << 1) | (surely_in ? 1u : 0u);
+                    ++cnt;
+                }
+            }
+            // the nearest node child is visited next, the others are pushed (in slot order)
+            int near = 0;
+            float knear = key[0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c)
+                if (key[c] < knear) { knear = key[c]; near = c; }
+            if (knear < INF) {
+                have_cur = true;
+                cur = (near == 0 ? refs[0] : (near == 1 ? refs[1] : (near == 2 ? refs[2] : refs[3]))) & RTX_WREF_INDEX;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c != near && key[c] < INF) {
+                        if (sp < RTX_BVH_STACK) {
+                            const uint32_t q = ANY ? 0u : (uint32_t)fminf(key[c] * qscale, qmax);
+                            stk[sp * RTX_BLOCK] = (refs[c] & RTX_WREF_INDEX) | (q << nbits);
+                            ++sp;
+                        } else {
+                            ovf = true;
+                        }
+                    }
+                }
+                if (ovf) { running = false; have_cur = false; }
+            }
+        }
+        // ---- flush (as traverse_ww): the parked candidates through the exact tests, every lane one of its own per round
+        const bool stalled = running && cnt > RTX_BVH_CAND - RTX_BVH4;
+        const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
+        if (__any(stalled) || holders >= RTX_BVH_FLUSH || !__any(running)) {
+            for (uint32_t i = 0; __any(i < cnt); ++i) {
+                if (i < cnt && !(ANY && best_ref != REF_NONE)) {   // any-hit: one occluder is enough
+                    const uint32_t c = cand[i * RTX_BLOCK];
+                    const int ref = (int)c >> 1;
+                    const bool surely_in = (c & 1u) != 0u;
+                    if (ref >= 0) {
+                        int pid, mat;
+                        TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                        if (surely_in || tri_bbox_hit(tr, r)) {
+                            WORK(++w_prims;)
+                            double t, be, ga;
+                            if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
+                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
+                            } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                                // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
+                                best_t = t;
+                                best_ref = ref;
+                            }
+                        }
+                    } else {
+                        const DSphere &sp_ = sc.spheres[~ref];
+                        V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                        double radius = sp_.r;
+                        if (surely_in || sphere_bbox_hit(cc, radius, r)) {
+                            WORK(++w_prims;)
+                            double t;
+                            if (ANY) {
+                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
+                            } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                                best_t = t;
+                                best_ref = ref;
+                            }
+                        }
+                    }
+                }
+            }
+            cnt = 0u;
+            bf = f32_above(best_t - tsh);
+            if (ANY && best_ref != REF_NONE) running = false;
+        }
+    }
+
+    // infinite prims last, in order (octree.rs:163-165,185-186)
+    if (active && !ovf) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            const DPlane &pl = sc.planes[p];
+            double t;
+            if (ANY) {
+                if (best_ref == REF_NONE && plane_hit(pl, r, t_lo, t_hi, &t)) best_ref = REF_PLANE | p;
+            } else if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                best_t = t;
+                best_ref = REF_PLANE | p;
+            }
+        }
+    }
+    hit->t = best_t;
+    hit->ref = best_ref;
+    *overflow = ovf;
+    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
+}
+
 template <int MODE>
 DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, double t_hi, Hit *hit, V3 *prod) {
     // MODE_CLOSEST has its own entry point (traverse_ww: wave-wide flushes, every lane must call it)
@@ -1042,9 +1233,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
                                                                           DCounters *counters, double *hit_t, int32_t *hit_ref) {
-    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : 1];
-    init_lds(s_stk);
+    __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (MODE == MODE_CLOSEST_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    if constexpr (MODE != MODE_CLOSEST_BVH) init_lds(s_stk);
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
     uint32_t slot = begin + (valid ? gid : 0u);
@@ -1071,6 +1262,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene
         const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
         traverse_ww<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit);
         if (degen) hit.ref = REF_RETRY;
+    } else if constexpr (MODE == MODE_CLOSEST_BVH) {
+        size_t cap = pool.cap;
+        const double *f = pool.f + slot;
+        Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
+                      : make_ray(v3(0, 0, 0), v3(0, 0, 1));
+        const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
+        bool ovf;
+        traverse_bvh<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit, &ovf);
+        if (degen || ovf) hit.ref = REF_RETRY;                          // (a full stack: the all-f64 walk answers the ray)
     } else if (valid) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
@@ -1335,9 +1535,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
-    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : 1];
-    init_lds(s_stk);
+    __shared__ uint32_t s_stk[MODE == MODE_ANY_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (MODE == MODE_ANY_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    if constexpr (MODE != MODE_ANY_BVH) init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     const uint32_t tries_shift = (uint32_t)__ffs((int)tries) - 1u;   // (no 64-bit division for the usual try counts)
     uint32_t group = pow2_tries ? (uint32_t)(gid >> tries_shift) : (uint32_t)(gid / tries);
@@ -1382,6 +1582,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
         if (valid) v = (hit.ref == REF_NONE && !degen) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
         if (degen) retry_append(sq, light, (uint32_t)gid, sample, counters);
         WORK(count_work(valid, hit, counters->work[1]);)
+    } else if constexpr (MODE == MODE_ANY_BVH) {
+        Hit hit;
+        const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_shadow_retry; counts as 0 here
+        bool ovf;
+        traverse_bvh<WW_ANY>(sc, r, valid && !degen, s_stk, s_cand, EPSILON, distance_to_light, &hit, &ovf);
+        const bool retry = degen || (valid && ovf);                     // (a full stack: the all-f64 walk answers the feeler)
+        if (valid) v = (hit.ref == REF_NONE && !retry) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
+        if (retry) retry_append(sq, light, (uint32_t)gid, sample, counters);
+        WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {
         Hit hit;
         V3 pr = v3(0, 0, 0);
@@ -1399,7 +1608,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene s
         WORK(count_work(true, hit, counters->work[1]);)
     }
     double inv_tries = 1.0 / (double)tries;
-    if (MODE == MODE_ANY && pow2_tries) {
+    if ((MODE == MODE_ANY || MODE == MODE_ANY_BVH) && pow2_tries) {
         // any-hit answers are 0 or 1: the group's sum is a population count (exact, like the butterfly below)
         const uint32_t ln = threadIdx.x & 63u;
         const unsigned long long clear = __ballot(valid && v.x != 0.0);
@@ -2172,9 +2381,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_resolve(DFrame fr, const double *
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, const double *origin, const double *direction,
                                                         int32_t *prim_id, double *t_out) {
-    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : 1];
-    init_lds(s_stk);
+    __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (MODE == MODE_CLOSEST_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    if constexpr (MODE != MODE_CLOSEST_BVH) init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (gid >= n) return;    // lanes that leave here simply drop out of the wave-wide votes below
     V3 o = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
@@ -2186,6 +2395,11 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
         const bool degen = degenerate_dir(r.dx, r.dy, r.dz);
         traverse_ww<WW_CLOSEST>(sc, r, !degen, s_stk, s_cand, T_MIN, inf(), &hit);
         if (degen) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    } else if constexpr (MODE == MODE_CLOSEST_BVH) {   // what k_closest<MODE_CLOSEST_BVH> + k_closest_retry do
+        const bool degen = degenerate_dir(r.dx, r.dy, r.dz);
+        bool ovf;
+        traverse_bvh<WW_CLOSEST>(sc, r, !degen, s_stk, s_cand, T_MIN, inf(), &hit, &ovf);
+        if (degen || ovf) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
     } else {
         traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     }
@@ -2284,8 +2498,12 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                            count, counters, hit_t, hit_ref);
     else
     {
-        hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
-                           counters, hit_t, hit_ref);
+        if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK))
+            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                               count, counters, hit_t, hit_ref);
+        else
+            hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
+                               counters, hit_t, hit_ref);
         hipLaunchKernelGGL(k_closest_retry, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
                            hit_ref);
     }
@@ -2305,6 +2523,7 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     const bool exact = (fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) != 0u;   // re-render after a retry-list overflow
     const bool coop = sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && !exact;
     const bool any_hit = sc.all_opaque != 0 && !exact;   // the any-hit kernels hand degenerate feelers to k_shadow_retry
+    const bool bvh = sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK);   // per-lane any-hit walks over the 4-wide hierarchy
     if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap), 0, sizeof(uint32_t), (hipStream_t)stream);
     if (exact)   // the all-f64 product walk answers every feeler, degenerate or not (all-opaque scenes: a product of zeros)
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
@@ -2317,9 +2536,16 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
         // queue entries empty, the per-lane kernel takes what is left
         hipLaunchKernelGGL(k_shadow_coop<true>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
-        hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+        if (bvh)
+            hipLaunchKernelGGL(k_shadow<MODE_ANY_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                               n_groups, tries, pow2, counters, acc);
+        else
+            hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                               n_groups, tries, pow2, counters, acc);
+    } else if (sc.all_opaque && bvh)
+        hipLaunchKernelGGL(k_shadow<MODE_ANY_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
-    } else if (sc.all_opaque)
+    else if (sc.all_opaque)
         hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk
@@ -2442,6 +2668,9 @@ void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double
     if (flags & RTX_FLAG_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_nearest<MODE_CLOSEST_REF>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
                            origin, direction, prim_id, t_out);
+    else if (sc.bvh4 && !(flags & RTX_FLAG_OCTREE_WALK))
+        hipLaunchKernelGGL(k_nearest<MODE_CLOSEST_BVH>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n, origin,
+                           direction, prim_id, t_out);
     else
         hipLaunchKernelGGL(k_nearest<MODE_CLOSEST>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n, origin,
                            direction, prim_id, t_out);

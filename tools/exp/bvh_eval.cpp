@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
     double ms = 1e30;
     for (int rep = 0; rep < (std::getenv("BVH_REPS") ? std::atoi(std::getenv("BVH_REPS")) : 1); ++rep) {   // best of BVH_REPS builds
         auto t0 = std::chrono::steady_clock::now();
-        rtx_build_wide_bvh(prims, centre, wide, &st, pool);
+        { std::vector<DNode4> b4; rtx_build_hierarchies(prims, centre, wide, b4, &st, pool); }
         ms = std::min(ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     const size_t n_nodes = wide.size() / RTX_WIDE;

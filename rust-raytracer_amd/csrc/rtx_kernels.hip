@@ -824,10 +824,13 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
 #define RTX_BVH_STACK 16
 #define RTX_BVH_CAND 8        // candidates a lane can park; a visit needs room for 4
 #ifndef RTX_BVH_STEPS
-#define RTX_BVH_STEPS 3       // node visits per lane and round before the wave looks at the parked candidates
+#define RTX_BVH_STEPS 6       // node visits per lane and round before the wave looks at the parked candidates (2: +30 %, 3..8: within 1.5 %)
 #endif
 #ifndef RTX_BVH_FLUSH
 #define RTX_BVH_FLUSH 24
+#endif
+#ifndef RTX_BVH_WAVES
+#define RTX_BVH_WAVES 5       // waves per SIMD of the kernels built on this walk: 96 VGPRs (at 6: 32 of them spilled, closest + shade 40.8 -> 37.1 ms)
 #endif
 template <int WW>
 DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_stack, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
@@ -1231,7 +1234,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 #define RTX_CLOSEST_WAVES 6
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK, RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
+__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_WAVES : RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
                                                                           DCounters *counters, double *hit_t, int32_t *hit_ref) {
     __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (MODE == MODE_CLOSEST_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
@@ -1533,7 +1536,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
 #define RTX_SHADOW_WAVES 6
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : RTX_SHADOW_WAVES) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
     __shared__ uint32_t s_stk[MODE == MODE_ANY_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (MODE == MODE_ANY_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];

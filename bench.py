@@ -257,7 +257,7 @@ def main():
             v = pmc.get(kname + "_valu") or {}
             frac = (v.get("busy") * v.get("lane_utilisation")) if v else None
             out["roofline"] = {
-                "bound": "valu", "kernel": {"k_shadow": "k_shadow_coop<false>", "k_trace": "k_closest<0> (+ k_shade)"}[kname],
+                "bound": "valu", "kernel": {"k_shadow": "k_shadow_coop<false>", "k_trace": "k_closest<5> (+ k_shade)"}[kname],
                 "achieved": frac * VALU_LANE_SLOTS if frac is not None else None, "peak": VALU_LANE_SLOTS,
                 "unit": "VALU lane-slots per cycle doing a lane's work (256 CUs x 4 SIMDs x 16 lanes)",
                 "frac": frac,

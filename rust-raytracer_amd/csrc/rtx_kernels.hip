@@ -821,7 +821,9 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
 // node child; the other node children go onto the lane's stack in LDS together with their entry distance, quantised DOWNWARDS into
 // the bits the node index leaves free, so that a pop can drop what lies behind the best hit by then.  A full stack (never seen:
 // 16 entries, 3.4 needed on average) sets *overflow and ends the walk: the caller hands the ray to the all-f64 walk.
-#define RTX_BVH_STACK 16
+#ifndef RTX_BVH_STACK
+#define RTX_BVH_STACK 16     // (3 in the forced-overflow test build, tests/test_gpu_variants.py)
+#endif
 #define RTX_BVH_CAND 8        // candidates a lane can park; a visit needs room for 4
 #ifndef RTX_BVH_STEPS
 #define RTX_BVH_STEPS 6       // node visits per lane and round before the wave looks at the parked candidates (2: +30 %, 3..8: within 1.5 %)
@@ -2384,7 +2386,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_resolve(DFrame fr, const double *
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, const double *origin, const double *direction,
                                                         int32_t *prim_id, double *t_out) {
-    __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
+    // (MODE_CLOSEST_BVH: the node stack of traverse_bvh, then the level stack of traverse_exact for the rays handed over)
+    __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (MODE == MODE_CLOSEST_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
     if constexpr (MODE != MODE_CLOSEST_BVH) init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;

@@ -336,6 +336,35 @@ def test_reference_order_flag_agrees(rtx, orc):
     assert (np.abs(a.astype(int) - b.astype(int)) <= 1).mean() >= 0.999
 
 
+def test_octree_walk_flag_agrees(rtx, orc):
+    """RTX_FLAG_OCTREE_WALK: the per-lane closest-hit and any-hit walks over the reference's octree (f32 twins) instead of the 4-wide SAH
+    hierarchy.  Both reach a superset of the prims a ray truly hits and decide each with the same exact f64 tests: the same t bit for
+    bit, the same prim but for exact-t ties, the same frames (1 shadow try: per-lane any-hit walk; 4: what the cooperative walk leaves)."""
+    flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32)
+    sc = rtx.Scene(flat)
+    assert sc.info().wide_nodes > 0
+    rng = np.random.default_rng(5)
+    n = 20000
+    o = np.tile(np.array([[0.0, -180.0, 60.0]]), (n, 1)) + rng.normal(0, 40.0, (n, 3))
+    tgt = np.array([[12.0, 58.0, 52.0]]) + rng.normal(0, 45.0, (n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ia, ta = sc.nearest_hits(o, d)
+    ib, tb = sc.nearest_hits(o, d, rtx.abi.FLAG_OCTREE_WALK)
+    io, to = orc.Scene(flat).nearest_hits(o, d)
+    assert np.array_equal(ta.view(np.uint64), tb.view(np.uint64)) and np.array_equal(ta.view(np.uint64), to.view(np.uint64))
+    assert (ia >= 0).mean() > 0.3
+    assert (ia == ib).mean() >= 0.9999 and (ia == io).mean() >= 0.9999
+    cam = cam_fn(160, 96)
+    for kw in (DET, dict(reflect_depth=3, refract_depth=3, shadow_samples=4, gloss_samples=1, pixel_samples=2, rng_mode=1, seed=2)):
+        a, ida, sta = sc.render(cam, rtx.options(**kw))
+        b, idb, stb = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_OCTREE_WALK, **kw))
+        assert sta.rays_total == stb.rays_total
+        assert (ida == idb).mean() >= 0.9999
+        assert (np.abs(a.astype(int) - b.astype(int)) <= 1).mean() >= 0.999
+    sc.close()
+
+
 def test_bad_arguments(rtx):
     flat, cam_fn = scenes.sphere_scene(rtx)
     sc = rtx.Scene(flat)

@@ -1,0 +1,40 @@
+"""Child process of tests/test_gpu_variants.py (not collected by pytest): renders small scenes with the library build named by
+RTX_LIB (a forced-failure build of rust-raytracer_amd/csrc) and compares them with the CPU oracle.  Prints OK on success."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes  # noqa: E402
+
+rtx = importlib.import_module("rust-raytracer_amd")
+orc = importlib.import_module("oracle.oracle")
+orc.build()
+assert os.path.basename(rtx.abi.LIB_PATH) == os.environ["RTX_LIB"], rtx.abi.LIB_PATH
+
+
+def compare(flat, cam, opt, what):
+    sc = rtx.Scene(flat)
+    rgba, ids, st = sc.render(cam, opt)
+    sc.close()
+    orgba, oids, ocn = orc.Scene(flat).render(cam, opt)
+    id_ok = float((ids == oids).mean())
+    rgb_ok = float((np.abs(rgba[..., :3].astype(int) - orgba[..., :3].astype(int)).max(axis=-1) <= 1).mean())
+    assert st.rays_total == ocn.rays_total, (what, st.rays_total, ocn.rays_total)
+    assert id_ok >= 0.9999 and rgb_ok >= 0.999, (what, id_ok, rgb_ok)
+    print("%s: ids %.5f rgb %.5f rays %d" % (what, id_ok, rgb_ok, st.rays_total))
+
+
+flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32)
+# closest hit + one feeler per light and lane (the per-lane any-hit walk)
+compare(flat, cam_fn(160, 96), rtx.options(reflect_depth=4, refract_depth=4, shadow_samples=1, gloss_samples=1, pixel_samples=1, rng_mode=0),
+        "deterministic, 1 shadow try")
+# 16 tries per hit point: the cooperative shadow walk; 4: groups of neighbouring hit points + the per-lane walk for the rest
+for tries in (16, 4):
+    compare(flat, cam_fn(96, 64), rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=tries, gloss_samples=1, pixel_samples=2,
+                                              rng_mode=1, seed=11), "philox, %d shadow tries" % tries)
+print("OK")

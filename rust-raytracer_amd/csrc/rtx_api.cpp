@@ -827,6 +827,9 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     // atomics).  Two shadow queues alternate: k_shade of step i waits until the shadow launches of step i - 2 have
     // read theirs.  The caller's stream joins w.aux[] before the resolve.
     const bool overlap = !(fr.flags & RTX_FLAG_SERIAL) && opt->shadow_samples > 0 && !s->lights.empty();
+    // the shadow feelers of this frame run in k_shadow_coop<false> beside the next step's closest-hit / shade launches: k_shade's small instance
+    if (overlap && s->d.all_opaque && s->d.wide && !(fr.flags & RTX_FLAG_NO_COOP) && opt->shadow_samples % 16u == 0u && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) && !std::getenv("RTX_GENERAL_SHADE"))
+        fr.flags |= RTX_FLAG_INTERNAL_SMALL_SHADE;
     hipEvent_t sq_free[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [queue][aux stream]
     const size_t n_aux = std::min<size_t>(2, s->lights.size());
     uint32_t step = 0;
@@ -1217,7 +1220,9 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane walk
     if (!bvh4_ok) ds.bvh4 = nullptr;   // the per-lane walks fall back to the octree
     ds.bvh4_node_bits = bvh4_bits;
-    ds.pad0_ = 0;
+    ds.shade_features = s->any_glossy ? RTX_SHADE_GLOSSY : 0u;
+    for (const rtx_material &m : materials)
+        if (m.kind == RTX_MAT_PHONG) ds.shade_features |= RTX_SHADE_PHONG;
     s->n_materials = d->n_materials;
     s->n_textures = d->n_textures;
     ds.n_planes = (int32_t)planes.size();

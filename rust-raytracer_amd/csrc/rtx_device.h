@@ -104,6 +104,8 @@ struct DImage {
     int64_t offset; // byte offset of the RGBA8 pixels in the atlas
 };
 
+#define RTX_SHADE_GLOSSY 1u   // some material has glossiness > f64::EPSILON (renderer.rs:155: Ray::perturb)
+#define RTX_SHADE_PHONG 2u    // some material is a PhongMaterial (phongmaterial.rs:33: powf(shininess))
 struct DScene {
     const DNode *nodes;
     const DNode32 *nodes32;
@@ -112,7 +114,7 @@ struct DScene {
     const DWideChild *wide;     // 16-wide hierarchy over the finite prims: node n = wide[16 n .. 16 n + 15], node 0 = root
     const DNode4 *bvh4;         // 4-wide hierarchy over the same prims, node 0 = root; NULL: the per-lane walks use the octree
     uint32_t bvh4_node_bits;    // bits of a stack entry that hold the node index (the rest: quantised entry distance)
-    uint32_t pad0_;
+    uint32_t shade_features;    // RTX_SHADE_*: what the scene's materials need of k_shade (0: the lean instance)
     const DTri *tris;
     const DTriShade *tri_shade;
     const DSphere *spheres;
@@ -178,6 +180,9 @@ struct DShadowQ {
 // reference's walk (k_shadow<MODE_PRODUCT>), which is valid for every feeler of every scene.  Set for the re-render of a frame
 // whose retry list overflowed (more degenerate feelers in one launch than the list holds).
 #define RTX_FLAG_INTERNAL_EXACT_SHADOWS 0x80000000u
+// internal bit: k_shade's small instance (see the kernel): set by the host for frames whose shadow feelers run in the cooperative kernel
+// beside the closest-hit / shade chain
+#define RTX_FLAG_INTERNAL_SMALL_SHADE 0x40000000u
 #define RTX_FLAG_PUBLIC_MASK 0xFu
 
 struct DCounters {

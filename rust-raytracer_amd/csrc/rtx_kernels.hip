@@ -1084,6 +1084,8 @@ DEV V3 cubemap_color(const DScene &sc, V3 dir) {                                
 }
 
 // ------------------------------------------------------------------------------ materials
+// PHONG = false: the instance for scenes without a Phong material (k_shade<false>), without the generic pow() of phongmaterial.rs:33.
+template <bool PHONG = true>
 DEV V3 material_sample(const DScene &sc, const rtx_material &m, V3 n, V3 i, V3 l, double u, double v) {
     V3 diffuse_c = v3(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
     if (m.kind == RTX_MAT_FLAT) return diffuse_c;                                        // flatmaterial.rs:11-13
@@ -1110,6 +1112,7 @@ DEV V3 material_sample(const DScene &sc, const rtx_material &m, V3 n, V3 i, V3 l
         double brdf = f * d * g / (n_dot_v * n_dot_l * PI);
         return scale(specular_c, m.k_s * brdf) + diffuse + ambient;
     }
+    if constexpr (!PHONG) return diffuse_c;   // (not reached: the host launches this instance for scenes without Phong materials only)
     V3 h = unit(l + i);                                                                  // phongmaterial.rs:24-36
     V3 ambient = scale(ambient_c, m.k_a);
     V3 diffuse = scale(scale(diffuse_c, m.k_d), dot(n, l)) * texc;
@@ -1355,7 +1358,18 @@ DEV uint32_t block_alloc(uint32_t c, uint32_t *counter, uint32_t *s_tmp /* >= 6 
 #ifndef RTX_SHADE_WAVES
 #define RTX_SHADE_WAVES 2
 #endif
-__global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
+#ifndef RTX_SHADE_WAVES_LEAN
+#define RTX_SHADE_WAVES_LEAN 5
+#endif
+// GENERAL = false: the SMALL instance, 96 VGPRs at 5 waves per SIMD (the general one: 208 at 2), for frames whose shadow feelers run in the
+// cooperative kernel next to it (RTX_FLAG_INTERNAL_SMALL_SHADE: 16 tries per hit point or a multiple, overlap on).  k_shadow_coop keeps six
+// 80-VGPR waves per SIMD resident and the VALUs 94 % busy; a workgroup of the general instance needs 208 VGPRs on all four SIMDs of a CU at
+// once and waits for them (9 ms per launch under overlap for 1.2 ms alone), the small one fits into the slot of one or two shadow waves.  It is
+// slower alone (spills: bunny 5.98 -> 7.6 ms if it were used there), so it runs only where the shadow kernel dominates: sponza frame 208.6 ->
+// 204.6 ms.  Compiled without the f64 pow / acos / sin / cos of Ray::perturb (glossy reflection) and of the Phong term, which would spill far
+// more: scenes that need them (DScene.shade_features != 0) always take the general instance.
+template <bool GENERAL>
+__global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHADE_WAVES_LEAN) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                      const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
                                                      double *acc, int32_t *prim_id_out) {
     __shared__ uint32_t s_tmp[8];
@@ -1454,7 +1468,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
         if (is_hit) {
             const rtx_light &lt = sc.lights[li];
             V3 l = unit(v3(lt.position[0], lt.position[1], lt.position[2]) - hp);
-            V3 smp = material_sample(sc, m, n, iv, l, hu, hv);
+#ifdef RTX_ABL_SHADE_NOBRDF
+            V3 smp = v3(dot(n, l), hu, hv);
+#else
+            V3 smp = material_sample<GENERAL>(sc, m, n, iv, l, hu, hv);
+#endif
             w = thr * (v3(lt.color[0], lt.color[1], lt.color[2]) * smp);
             if (fr.shadow_samples == 0u) acc_add(acc, sample, w);                        // renderer.rs:191: shadow = one
             else emit = true;
@@ -1481,10 +1499,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
 
     // a child whose depth counter reaches 0 returns zero at renderer.rs:106 and is not a ray
     bool spawn_reflect = reflective && reflect_depth > 1u && refract_depth > 0u;
-    bool glossy = m.kind != RTX_MAT_FLAT && m.glossiness > F64_EPSILON;
+    bool glossy = GENERAL && m.kind != RTX_MAT_FLAT && m.glossiness > F64_EPSILON;
     bool spawn_transmit = refractive && refract_depth > 1u && reflect_depth > 0u;
     uint32_t n_reflect = spawn_reflect ? (glossy ? fr.gloss_samples : 1u) : 0u;
     uint32_t n_children = n_reflect + (spawn_transmit ? 1u : 0u);
+#ifdef RTX_ABL_SHADE_NOSPAWN
+    n_children = 0u; n_reflect = 0u; spawn_transmit = false;
+#endif
     uint32_t cs = block_alloc(n_children, &counters->pool_tail, s_tmp);
     if (n_children && cs + n_children > pool.cap) {
         counters->overflow = 1u;
@@ -1498,7 +1519,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_SHADE_WAVES) k_shade(DScene sc,
     if (n_reflect && !glossy) {   // mirror reflection (renderer.rs:164)
         pool_store(pool, cs, hp, rdir, scale(scale(thr, m.k_sg), reflect_fresnel), child_key(key, CODE_MIRROR), sample,
                    child_flags_reflect | ((uint32_t)RAY_REFLECT << RAYF_TYPE_SHIFT));
-    } else if (n_reflect) {       // glossy reflection: gloss_samples perturbed rays, averaged (renderer.rs:155-161)
+    } else if (GENERAL && n_reflect) {       // glossy reflection: gloss_samples perturbed rays, averaged (renderer.rs:155-161)
         double inv_g = 1.0 / (double)fr.gloss_samples;
         for (uint32_t g = 0; g < n_reflect; ++g) {
             // Ray::perturb (ray.rs:68-81) with Vec3::random (vec3.rs:112-126)
@@ -1681,7 +1702,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_retry(DScene sc, DFrame fr
 #define RTX_COOP_STACK 48     // words: 24 spilled levels of 2 words (host checks 2 * depth + 2 <= 24)
 #define RTX_COOP_QUEUE 40     // RTX_COOP_QT - 1 + 2 * 16 at most
 #ifndef RTX_COOP_QT
-#define RTX_COOP_QT 6      // drain the candidate queue once it holds this many primitives
+#define RTX_COOP_QT 1      // drain the candidate queue once it holds this many primitives (with the DP-collapsed lists: 1: 176.2, 2..4: 177.5, 6: 178.2, 9: 180.3 ms; an occluder found early ends walks early)
 #endif
 #ifndef RTX_COOP_WAVES
 #define RTX_COOP_WAVES 6     // one hit point per group: 80 VGPRs (5 spilled around the exact tests) and 26 KB of LDS; 194.8 against 198.5 ms at 5
@@ -2515,8 +2536,12 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     }
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t, hit_ref,
-                       sq, counters, acc, prim_id_out);
+    if (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE))
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out);
 }
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc) {

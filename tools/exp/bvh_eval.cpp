@@ -3,6 +3,7 @@
 // light's sampling cube), counting what k_shadow_coop counts: node visits per group, own-box tests and exact tests per feeler.
 // No GPU.  usage: bvh_eval scene.bin [groups]     (scene.bin: tools/exp/dump_scene.py)
 // build: g++ -O2 -std=c++17 -pthread -I rust-raytracer_amd/csrc -I include -o /tmp/bvh/bvh_eval tools/exp/bvh_eval.cpp
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -18,6 +19,7 @@ static double dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 struct Seg { V o, d, inv; double tmax; bool alive; };
 
+static double g_tn;   // entry distance of the last seg_box() that passed
 static bool seg_box(const Seg &s, const float *lo, const float *hi, const double *c) {
     double t0 = 0.0, t1 = s.tmax;
     const double o[3] = {s.o.x - c[0], s.o.y - c[1], s.o.z - c[2]}, inv[3] = {s.inv.x, s.inv.y, s.inv.z};
@@ -27,6 +29,7 @@ static bool seg_box(const Seg &s, const float *lo, const float *hi, const double
         if (ta > t0) t0 = ta;
         if (tb < t1) t1 = tb;
     }
+    g_tn = t0;
     return t0 <= t1;
 }
 static bool seg_tri(const Seg &s, const double *v) {
@@ -142,17 +145,21 @@ int main(int argc, char **argv) {
                 { int fc = 0; for (int s = 0; s < RTX_WIDE; ++s) fc += (wide[(size_t)nd * RTX_WIDE + s].ref & RTX_WREF_KIND) != RTX_WREF_EMPTY; by_fill[fc] += 1; }
                 ++visits;
                 std::vector<uint32_t> kids;
+                std::vector<double> kid_tn;
                 for (int s = 0; s < RTX_WIDE; ++s) {
                     const DWideChild &c = wide[(size_t)nd * RTX_WIDE + s];
                     uint32_t kind = c.ref & RTX_WREF_KIND;
                     if (kind == RTX_WREF_EMPTY) continue;
                     bool any = false;
-                    for (int k = 0; k < 16 && !any; ++k) any = seg_box(seg[k], c.lo, c.hi, centre);   // the beam is the hull of ALL 16 (dead ones too)
+                    double tn_min = 1e300;
+                    for (int k = 0; k < 16; ++k)
+                        if (seg_box(seg[k], c.lo, c.hi, centre)) { any = true; tn_min = std::min(tn_min, g_tn); }   // the beam is the hull of ALL 16 (dead ones too)
                     if (!any) continue;
                     if (kind == RTX_WREF_NODE) {
                         int below = 0;
                         for (int q = 0; q < s; ++q) below += (wide[(size_t)nd * RTX_WIDE + q].ref & RTX_WREF_KIND) == RTX_WREF_NODE;
                         kids.push_back(c.first_node + (uint32_t)below);
+                        kid_tn.push_back(tn_min);
                     } else {
                         s_queued += 1;
                         for (int k = 0; k < 16; ++k) {
@@ -163,6 +170,19 @@ int main(int argc, char **argv) {
                             if (seg_tri(seg[k], &tv[(size_t)(c.ref & RTX_WREF_INDEX) * 9])) { seg[k].alive = false; --live; }
                         }
                     }
+                }
+                static const int order_mode = std::getenv("BVH_ORDER") ? std::atoi(std::getenv("BVH_ORDER")) : 0;
+                if (order_mode == 1) {   // nearest child first (all children sorted by entry distance)
+                    std::vector<size_t> ix(kids.size());
+                    for (size_t q = 0; q < ix.size(); ++q) ix[q] = q;
+                    std::sort(ix.begin(), ix.end(), [&](size_t a, size_t b) { return kid_tn[a] < kid_tn[b]; });
+                    std::vector<uint32_t> k2;
+                    for (size_t q : ix) k2.push_back(kids[q]);
+                    kids = k2;
+                } else if (order_mode == 2 && kids.size() > 1) {   // only the nearest child moved to the front
+                    size_t m = 0;
+                    for (size_t q = 1; q < kids.size(); ++q) if (kid_tn[q] < kid_tn[m]) m = q;
+                    std::swap(kids[0], kids[m]);
                 }
                 for (size_t q = kids.size(); q-- > 0;) { stack.push_back(kids[q]); dstack.push_back(dep + 1); }
             }

@@ -9,7 +9,7 @@ for v in "$@"; do
   lib=librtx_$v.so; [ "$v" = base ] && lib=librtx.so
   line="$v:"
   for w in $WL; do
-    RTX_LIB=$lib timeout -k 10 100 python bench.py --workload $w --cpu-blocks 0 --steps 3 --warmup 1 --serial > $O/vw_${v}_$w.json 2> $O/vw_${v}_$w.err || { echo "$v $w failed"; tail -5 $O/vw_${v}_$w.err; exit 1; }
+    RTX_LIB=$lib timeout -k 10 100 python bench.py --workload $w --cpu-blocks 0 --steps 3 --warmup 1 ${RTX_WL_ARGS---serial} > $O/vw_${v}_$w.json 2> $O/vw_${v}_$w.err || { echo "$v $w failed"; tail -5 $O/vw_${v}_$w.err; exit 1; }
     line="$line $(python - "$w" "$O/vw_${v}_$w.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -1202,6 +1202,23 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     lap("hierarchies (SAH)");
     up.submit(wide, &ds.wide);
     up.submit(bvh4, &ds.bvh4);
+    // the inverse of the leaf lists (which leaves list a prim), for the two-phase shadow product of scenes with transmissive materials
+    std::vector<int32_t> prim_leaf_begin, prim_leaves;
+    if (!all_opaque && bvh4_ok) {
+        prim_leaf_begin.assign((size_t)n_fin + 1, 0);
+        for (int32_t e : oct.entries) ++prim_leaf_begin[(size_t)e + 1];
+        for (int i = 0; i < n_fin; ++i) prim_leaf_begin[(size_t)i + 1] += prim_leaf_begin[(size_t)i];
+        prim_leaves.resize(oct.entries.size());
+        std::vector<int32_t> fill(prim_leaf_begin.begin(), prim_leaf_begin.end() - 1);
+        for (size_t i = 0; i < n_nodes; ++i) {
+            const FNode &hn = oct.nodes[i];
+            if (hn.first_child >= 0) continue;
+            for (int e = hn.ebegin; e < hn.ebegin + hn.ecount; ++e) prim_leaves[(size_t)fill[(size_t)oct.entries[(size_t)e]]++] = (int32_t)i;
+        }
+        up.submit(prim_leaf_begin, &ds.prim_leaf_begin);
+        up.submit(prim_leaves, &ds.prim_leaves);
+        lap("inverse leaf lists");
+    }
     if ((st = up.finish(s.get()))) return cleanup(st);
     DNode32 *d_nodes32 = nullptr;
     DEntry32 *d_entries32 = nullptr;

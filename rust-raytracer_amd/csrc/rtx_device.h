@@ -113,6 +113,10 @@ struct DScene {
     const int32_t *leaf_refs;   // >= 0: triangle index, < 0: ~sphere index
     const DWideChild *wide;     // 16-wide hierarchy over the finite prims: node n = wide[16 n .. 16 n + 15], node 0 = root
     const DNode4 *bvh4;         // 4-wide hierarchy over the same prims, node 0 = root; NULL: the per-lane walks use the octree
+    // the inverse of the octree's leaf lists, per finite prim id: the leaves (node indices) that list it = prim_leaves[prim_leaf_begin[id] ..
+    // prim_leaf_begin[id + 1]); built for scenes with transmissive materials only (the two-phase shadow product), else NULL
+    const int32_t *prim_leaf_begin;
+    const int32_t *prim_leaves;
     uint32_t bvh4_node_bits;    // bits of a stack entry that hold the node index (the rest: quantised entry distance)
     uint32_t shade_features;    // RTX_SHADE_*: what the scene's materials need of k_shade (0: the lean instance)
     const DTri *tris;

@@ -248,7 +248,9 @@ DEV bool plane_hit(const DPlane &pl, const Ray &r, double t_min, double t_max, d
 // MODE_PRODUCT:      shadow feeler with transmissive materials: every candidate of the
 //                    multiset, duplicates included (renderer.rs:209-217), order-free product.
 // MODE_CLOSEST_BVH / MODE_ANY_BVH: MODE_CLOSEST / MODE_ANY over the 4-wide hierarchy instead of the octree (traverse_bvh).
-enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4, MODE_CLOSEST_BVH = 5, MODE_ANY_BVH = 6 };
+// MODE_PRODUCT_BVH: MODE_PRODUCT_FAST's answer in two phases: the distinct hit prims over the 4-wide hierarchy, then their multiplicities.
+enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4, MODE_CLOSEST_BVH = 5, MODE_ANY_BVH = 6,
+       MODE_PRODUCT_BVH = 7 };
 
 struct Hit {
     double t;
@@ -834,11 +836,25 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
 #ifndef RTX_BVH_WAVES
 #define RTX_BVH_WAVES 5       // waves per SIMD of the kernels built on this walk: 96 VGPRs (at 6: 32 of them spilled, closest + shade 40.8 -> 37.1 ms)
 #endif
+//   WW_PRODUCT: the shadow product of scenes with transmissive materials (renderer.rs:209-217), in two phases.  The reference multiplies
+// transmission() once per (reached leaf, entry of the leaf whose own bbox and primitive tests pass): the product is  PROD over the
+// distinct prims p the feeler hits of  T(p) ^ m(p),  m(p) = number of leaves that list p and that the reference's walk reaches.  Phase 1
+// finds the distinct hit prims with this walk (every candidate in [t_lo, t_hi], no best hit, no early end; refs kept in a per-lane LDS list);
+// phase 2 counts, for each of them, the leaves listing it (DScene.prim_leaves, the inverse of the octree's leaf lists) that the walk
+// reaches: for a feeler with a finite inverse direction that is "the leaf's own box passes BBox::intersects" (child boxes are nested
+// exactly and the test is monotone in the box, see traverse_ww: the decision is the same one, f32 where the box is clearly hit or
+// missed, the reference's f64 test on the stored box in between).  A root that is a leaf is never tested (octree.rs:149,177).  The
+// octree walk it replaces fetched 55 nodes and 125 leaf entries and ran 20 exact tests per heptoroid feeler, most of them copies.
+// *fallback: the caller must run the all-f64 walk (an infinite inverse direction component, more than RTX_BVH_HITS distinct hit prims,
+// a full stack).
+#ifndef RTX_BVH_HITS
+#define RTX_BVH_HITS 6      // (1 in the forced-overflow test build, tests/test_gpu_variants.py)
+#endif
 template <int WW>
 DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_stack, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
-                      bool *overflow) {
-    static_assert(WW == WW_CLOSEST || WW == WW_ANY, "the shadow product needs the reference's octree (traverse_ww<WW_PRODUCT>)");
-    constexpr bool ANY = WW == WW_ANY;
+                      bool *overflow, uint32_t *s_hits = nullptr, V3 *prod = nullptr) {
+    constexpr bool PRODUCT = WW == WW_PRODUCT;
+    constexpr bool ANY = WW == WW_ANY || PRODUCT;   // the window is [t_lo, t_hi] for every candidate, nothing is culled by a best hit
     uint32_t *stk = s_stack + threadIdx.x;   // stride RTX_BLOCK
     uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
     double best_t = ANY ? t_hi : inf();      // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
@@ -867,8 +883,11 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
 
     uint32_t sp = 0u, cnt = 0u, cur = 0u;
     bool running = active && !re.miss;   // a ray that misses the scene's cube has no finite candidate
+    bool ovf = PRODUCT && active && !finite_dir;   // 0 * inf = NaN slab distances: the all-f64 walk
+    if (ovf) running = false;
     bool have_cur = running;             // the root (octree.rs:149,177 never tests the root's box; neither does this walk)
-    bool ovf = false;
+    uint32_t n_hits = 0u;                // WW_PRODUCT: distinct prims hit so far
+    uint32_t *hits = PRODUCT ? s_hits + threadIdx.x : nullptr;   // stride RTX_BLOCK
     const float INF = __int_as_float(0x7F800000);
 
     for (;;) {
@@ -943,7 +962,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
         const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
         if (__any(stalled) || holders >= RTX_BVH_FLUSH || !__any(running)) {
             for (uint32_t i = 0; __any(i < cnt); ++i) {
-                if (i < cnt && !(ANY && best_ref != REF_NONE)) {   // any-hit: one occluder is enough
+                if (i < cnt && !(ANY && !PRODUCT && best_ref != REF_NONE) && !ovf) {   // any-hit: one occluder is enough
                     const uint32_t c = cand[i * RTX_BLOCK];
                     const int ref = (int)c >> 1;
                     const bool surely_in = (c & 1u) != 0u;
@@ -953,7 +972,12 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                         if (surely_in || tri_bbox_hit(tr, r)) {
                             WORK(++w_prims;)
                             double t, be, ga;
-                            if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
+                            if (PRODUCT) {
+                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
+                                    if (n_hits < RTX_BVH_HITS) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
+                                    else ovf = true;
+                                }
+                            } else if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
                             } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
                                 // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
@@ -968,7 +992,12 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                         if (surely_in || sphere_bbox_hit(cc, radius, r)) {
                             WORK(++w_prims;)
                             double t;
-                            if (ANY) {
+                            if (PRODUCT) {
+                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) {
+                                    if (n_hits < RTX_BVH_HITS) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
+                                    else ovf = true;
+                                }
+                            } else if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
                             } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                                 best_t = t;
@@ -980,7 +1009,57 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
             }
             cnt = 0u;
             bf = f32_above(best_t - tsh);
-            if (ANY && best_ref != REF_NONE) running = false;
+            if ((ANY && !PRODUCT && best_ref != REF_NONE) || ovf) running = false;
+        }
+    }
+
+    // ---- WW_PRODUCT, phase 2: every distinct hit prim counts once per reached leaf that lists it
+    V3 acc = v3(1.0, 1.0, 1.0);   // renderer.rs:211
+    if constexpr (PRODUCT) {
+        const bool root_is_leaf = sc.nodes32[0].aux != 0xFFFFFFFFu;
+        bool zero = false;
+        for (uint32_t h = 0; h < n_hits && !ovf && !zero; ++h) {
+            const int ref = (int)hits[h * RTX_BLOCK];
+            int pid, mat;
+            if (ref >= 0) {
+                const long long ids = __double_as_longlong(reinterpret_cast<const double *>(sc.tris + ref)[9]);   // (prim_id, material)
+                pid = (int)(ids & 0xFFFFFFFFLL);
+                mat = (int)(ids >> 32);
+            } else {
+                pid = sc.spheres[~ref].prim_id;
+                mat = sc.spheres[~ref].material;
+            }
+            uint32_t m = 1u;
+            if (!root_is_leaf) {
+                m = 0u;
+                const int e0 = sc.prim_leaf_begin[pid], e1 = sc.prim_leaf_begin[pid + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const uint32_t leaf = (uint32_t)sc.prim_leaves[e];
+                    const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + leaf);
+                    const float4 qa = nq[0], qb = nq[1];
+                    const float pnx = r.sx ? qa.x : qa.w, pfx = r.sx ? qa.w : qa.x;
+                    const float pny = r.sy ? qa.y : qb.x, pfy = r.sy ? qb.x : qa.y;
+                    const float pnz = r.sz ? qa.z : qb.y, pfz = r.sz ? qb.y : qa.z;
+                    // the box widened by delta missed => the f64 test fails (as the octree walk descends)
+                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(pnx, ix, cnx), 0.0f), fmaf(pny, iy, cny)), fmaf(pnz, iz, cnz));
+                    const float hi = fminf(fminf(fmaf(pfx, ix, cfx), fmaf(pfy, iy, cfy)), fmaf(pfz, iz, cfz));
+                    if (!(lo <= hi)) continue;
+                    // the box shrunk by delta passed => the f64 test passes; in between: the reference's test on the stored box
+                    bool reached = surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
+                                              fmaf(pfz, iz, cnz));
+                    if (!reached) {
+                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + leaf);
+                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                        double tn, tf;
+                        reached = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf);
+                    }
+                    m += reached ? 1u : 0u;
+                }
+            }
+            const rtx_material &mt = sc.materials[mat];
+            const V3 tr_ = mt.kind == RTX_MAT_FLAT ? v3(0.0, 0.0, 0.0) : v3(mt.transmission[0], mt.transmission[1], mt.transmission[2]);
+            for (uint32_t k = 0; k < m; ++k) acc = acc * tr_;
+            zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
         }
     }
 
@@ -989,7 +1068,13 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
         for (int p = 0; p < sc.n_planes; ++p) {
             const DPlane &pl = sc.planes[p];
             double t;
-            if (ANY) {
+            if (PRODUCT) {
+                if (plane_hit(pl, r, t_lo, t_hi, &t)) {
+                    const rtx_material &m = sc.materials[pl.material];
+                    if (m.kind == RTX_MAT_FLAT) acc = acc * v3(0.0, 0.0, 0.0);
+                    else acc = acc * v3(m.transmission[0], m.transmission[1], m.transmission[2]);
+                }
+            } else if (ANY) {
                 if (best_ref == REF_NONE && plane_hit(pl, r, t_lo, t_hi, &t)) best_ref = REF_PLANE | p;
             } else if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                 best_t = t;
@@ -1000,6 +1085,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
     hit->t = best_t;
     hit->ref = best_ref;
     *overflow = ovf;
+    if (PRODUCT) *prod = acc;
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 }
 
@@ -1562,11 +1648,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
 #define RTX_PRODUCT_WAVES 5   // the shadow product walk (scenes with transmissive materials): 96 VGPRs, no spills; heptoroid 1 420 -> 1 371 ms against 6
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_FAST ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES)) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_FAST || MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES)) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
-    __shared__ uint32_t s_stk[MODE == MODE_ANY_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (MODE == MODE_ANY_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
-    if constexpr (MODE != MODE_ANY_BVH) init_lds(s_stk);
+    constexpr bool BVH = MODE == MODE_ANY_BVH || MODE == MODE_PRODUCT_BVH;
+    // (MODE_PRODUCT_BVH: the node stack of traverse_bvh, then the level stack of traverse_exact for the feelers handed over)
+    __shared__ uint32_t s_stk[BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    __shared__ uint32_t s_hits[MODE == MODE_PRODUCT_BVH ? RTX_BVH_HITS * RTX_BLOCK : 1];
+    if constexpr (!BVH) init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     const uint32_t tries_shift = (uint32_t)__ffs((int)tries) - 1u;   // (no 64-bit division for the usual try counts)
     uint32_t group = pow2_tries ? (uint32_t)(gid >> tries_shift) : (uint32_t)(gid / tries);
@@ -1619,6 +1708,17 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
         const bool retry = degen || (valid && ovf);                     // (a full stack: the all-f64 walk answers the feeler)
         if (valid) v = (hit.ref == REF_NONE && !retry) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
         if (retry) retry_append(sq, light, (uint32_t)gid, sample, counters);
+        WORK(count_work(valid, hit, counters->work[1]);)
+    } else if constexpr (MODE == MODE_PRODUCT_BVH) {
+        Hit hit;
+        V3 pr = v3(0, 0, 0);
+        bool fb = false;
+        traverse_bvh<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit, &fb, s_hits, &pr);
+        if (valid) v = pr;
+        if (valid && fb) {   // axis-parallel feeler, more distinct hit prims than the list holds, a full stack: the all-f64 restatement
+            Hit h2;
+            traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, distance_to_light, &h2, &v);
+        }
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {
         Hit hit;
@@ -2445,12 +2545,13 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_t n, const double *origin, const double *target,
                                                                 double *out) {
-    __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[MODE == MODE_PRODUCT_FAST ? RTX_CAND_WORDS : 1];
-    init_lds(s_stk);
+    __shared__ uint32_t s_stk[MODE == MODE_PRODUCT_BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_PRODUCT_FAST ? RTX_CAND_WORDS : (MODE == MODE_PRODUCT_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    __shared__ uint32_t s_hits[MODE == MODE_PRODUCT_BVH ? RTX_BVH_HITS * RTX_BLOCK : 1];
+    if constexpr (MODE != MODE_PRODUCT_BVH) init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (MODE != MODE_PRODUCT_FAST && gid >= n) return;
-    const bool act = gid < n;   // MODE_PRODUCT_FAST: every lane of the wave takes part in the while-while walk
+    if (MODE != MODE_PRODUCT_FAST && MODE != MODE_PRODUCT_BVH && gid >= n) return;
+    const bool act = gid < n;   // MODE_PRODUCT_FAST / _BVH: every lane of the wave takes part in the while-while walk
     const int64_t g = act ? gid : 0;
     V3 p = v3(origin[g * 3], origin[g * 3 + 1], origin[g * 3 + 2]);
     V3 s = v3(target[g * 3], target[g * 3 + 1], target[g * 3 + 2]);
@@ -2459,7 +2560,11 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_
     double dist = len(s - p);
     Hit hit;
     V3 v = v3(0, 0, 0);
-    if constexpr (MODE == MODE_PRODUCT_FAST) {   // what k_shadow<MODE_PRODUCT_FAST> runs per feeler
+    if constexpr (MODE == MODE_PRODUCT_BVH) {   // what k_shadow<MODE_PRODUCT_BVH> runs per feeler
+        bool fb = false;
+        traverse_bvh<WW_PRODUCT>(sc, r, act, s_stk, s_cand, EPSILON, dist, &hit, &fb, s_hits, &v);
+        if (act && fb) traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, dist, &hit, &v);
+    } else if constexpr (MODE == MODE_PRODUCT_FAST) {   // what k_shadow<MODE_PRODUCT_FAST> runs per feeler
         bool fb = false;
         traverse_ww<WW_PRODUCT>(sc, r, act, s_stk, s_cand, EPSILON, dist, &hit, &v, &fb);
         if (act && fb) traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, dist, &hit, &v);
@@ -2584,6 +2689,9 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
                            n_groups, tries, pow2, counters, acc);
     else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                           n_groups, tries, pow2, counters, acc);
+    else if (bvh && sc.prim_leaves)   // the distinct hit prims over the 4-wide hierarchy, then their multiplicities
+        hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     else
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_FAST>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
@@ -2716,6 +2824,9 @@ void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, cons
     if (flags & RTX_FLAG_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
                            origin, target, out);
+    else if (sc.bvh4 && sc.prim_leaves && !(flags & RTX_FLAG_OCTREE_WALK))
+        hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT_BVH>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc,
+                           n, origin, target, out);
     else
         hipLaunchKernelGGL(k_shadow_products<MODE_PRODUCT_FAST>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc,
                            n, origin, target, out);

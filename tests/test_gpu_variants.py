@@ -9,9 +9,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = {
-    # traverse_bvh with a 3-entry stack: most rays overflow it and are answered by the all-f64 walks (k_closest_retry, the shadow
-    # retry list) -- the hand-off a full 16-entry stack would take
-    "librtx_smallstack.so": "-DRTX_BVH_STACK=3",
+    # traverse_bvh with a 3-entry stack and a 1-entry list of distinct hit prims: most rays overflow them and are answered by the
+    # all-f64 walks (k_closest_retry, the shadow retry list, traverse_exact<MODE_PRODUCT>) -- the hand-offs of a full stack / list
+    "librtx_smallstack.so": "-DRTX_BVH_STACK=3 -DRTX_BVH_HITS=1",
     # k_shadow_coop: every 7th tentative hit fails its deferred f64 entry-bbox confirmation and the feeler goes to the retry list
     "librtx_failconfirm.so": "-DRTX_DEBUG_FAIL_CONFIRM=7",
 }

@@ -37,4 +37,8 @@ compare(flat, cam_fn(160, 96), rtx.options(reflect_depth=4, refract_depth=4, sha
 for tries in (16, 4):
     compare(flat, cam_fn(96, 64), rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=tries, gloss_samples=1, pixel_samples=2,
                                               rng_mode=1, seed=11), "philox, %d shadow tries" % tries)
+# a transmissive material: the two-phase shadow product (distinct hit prims over the 4-wide hierarchy, then their multiplicities)
+flat_t, cam_fn_t = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=True)
+compare(flat_t, cam_fn_t(96, 64), rtx.options(reflect_depth=4, refract_depth=4, shadow_samples=2, gloss_samples=1, pixel_samples=1, rng_mode=1, seed=4),
+        "transmissive, 2 shadow tries")
 print("OK")

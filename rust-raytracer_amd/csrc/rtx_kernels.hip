@@ -845,10 +845,10 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
 // exactly and the test is monotone in the box, see traverse_ww: the decision is the same one, f32 where the box is clearly hit or
 // missed, the reference's f64 test on the stored box in between).  A root that is a leaf is never tested (octree.rs:149,177).  The
 // octree walk it replaces fetched 55 nodes and 125 leaf entries and ran 20 exact tests per heptoroid feeler, most of them copies.
-// *fallback: the caller must run the all-f64 walk (an infinite inverse direction component, more than RTX_BVH_HITS distinct hit prims,
-// a full stack).
+// A lane's list holds RTX_BVH_HITS refs; when one is full the wave runs phase 2 on what all lists hold and goes on.
+// *overflow: the caller must run the all-f64 walk (an infinite inverse direction component, a full stack).
 #ifndef RTX_BVH_HITS
-#define RTX_BVH_HITS 6      // (1 in the forced-overflow test build, tests/test_gpu_variants.py)
+#define RTX_BVH_HITS 6      // (1 in the forced-failure test build, tests/test_gpu_variants.py: phase 2 after every hit)
 #endif
 template <int WW>
 DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_stack, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
@@ -889,6 +889,58 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
     uint32_t n_hits = 0u;                // WW_PRODUCT: distinct prims hit so far
     uint32_t *hits = PRODUCT ? s_hits + threadIdx.x : nullptr;   // stride RTX_BLOCK
     const float INF = __int_as_float(0x7F800000);
+
+    // ---- WW_PRODUCT, phase 2: every distinct hit prim counts once per reached leaf that lists it.  Run by all lanes together, on what
+    // their lists hold: when a lane's list is full (before it would overflow) and after the walk.
+    V3 acc = v3(1.0, 1.0, 1.0);   // renderer.rs:211
+    bool zero = false;            // ... has reached exactly (0,0,0): finite factors, it stays there
+    auto count_hits = [&]() {
+        const bool root_is_leaf = sc.nodes32[0].aux != 0xFFFFFFFFu;
+        for (uint32_t h = 0; h < n_hits && !ovf && !zero; ++h) {
+            const int ref = (int)hits[h * RTX_BLOCK];
+            int pid, mat;
+            if (ref >= 0) {
+                const long long ids = __double_as_longlong(reinterpret_cast<const double *>(sc.tris + ref)[9]);   // (prim_id, material)
+                pid = (int)(ids & 0xFFFFFFFFLL);
+                mat = (int)(ids >> 32);
+            } else {
+                pid = sc.spheres[~ref].prim_id;
+                mat = sc.spheres[~ref].material;
+            }
+            uint32_t m = 1u;
+            if (!root_is_leaf) {
+                m = 0u;
+                const int e0 = sc.prim_leaf_begin[pid], e1 = sc.prim_leaf_begin[pid + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const uint32_t leaf = (uint32_t)sc.prim_leaves[e];
+                    const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + leaf);
+                    const float4 qa = nq[0], qb = nq[1];
+                    const float pnx = r.sx ? qa.x : qa.w, pfx = r.sx ? qa.w : qa.x;
+                    const float pny = r.sy ? qa.y : qb.x, pfy = r.sy ? qb.x : qa.y;
+                    const float pnz = r.sz ? qa.z : qb.y, pfz = r.sz ? qb.y : qa.z;
+                    // the box widened by delta missed => the f64 test fails (as the octree walk descends)
+                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(pnx, ix, cnx), 0.0f), fmaf(pny, iy, cny)), fmaf(pnz, iz, cnz));
+                    const float hi = fminf(fminf(fmaf(pfx, ix, cfx), fmaf(pfy, iy, cfy)), fmaf(pfz, iz, cfz));
+                    if (!(lo <= hi)) continue;
+                    // the box shrunk by delta passed => the f64 test passes; in between: the reference's test on the stored box
+                    bool reached = surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
+                                              fmaf(pfz, iz, cnz));
+                    if (!reached) {
+                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + leaf);
+                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                        double tn, tf;
+                        reached = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf);
+                    }
+                    m += reached ? 1u : 0u;
+                }
+            }
+            const rtx_material &mt = sc.materials[mat];
+            const V3 tr_ = mt.kind == RTX_MAT_FLAT ? v3(0.0, 0.0, 0.0) : v3(mt.transmission[0], mt.transmission[1], mt.transmission[2]);
+            for (uint32_t k = 0; k < m; ++k) acc = acc * tr_;
+            zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
+        }
+        n_hits = 0u;
+    };
 
     for (;;) {
         if (!__any(running || cnt > 0u)) break;
@@ -962,7 +1014,10 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
         const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
         if (__any(stalled) || holders >= RTX_BVH_FLUSH || !__any(running)) {
             for (uint32_t i = 0; __any(i < cnt); ++i) {
-                if (i < cnt && !(ANY && !PRODUCT && best_ref != REF_NONE) && !ovf) {   // any-hit: one occluder is enough
+                if constexpr (PRODUCT) {
+                    if (__any(n_hits >= RTX_BVH_HITS)) count_hits();   // a round adds at most one hit per lane
+                }
+                if (i < cnt && !(ANY && !PRODUCT && best_ref != REF_NONE) && !ovf && !zero) {   // any-hit: one occluder is enough
                     const uint32_t c = cand[i * RTX_BLOCK];
                     const int ref = (int)c >> 1;
                     const bool surely_in = (c & 1u) != 0u;
@@ -973,10 +1028,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                             WORK(++w_prims;)
                             double t, be, ga;
                             if (PRODUCT) {
-                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) {
-                                    if (n_hits < RTX_BVH_HITS) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
-                                    else ovf = true;
-                                }
+                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
                             } else if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
                             } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
@@ -993,10 +1045,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                             WORK(++w_prims;)
                             double t;
                             if (PRODUCT) {
-                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) {
-                                    if (n_hits < RTX_BVH_HITS) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
-                                    else ovf = true;
-                                }
+                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
                             } else if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
                             } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
@@ -1009,60 +1058,11 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
             }
             cnt = 0u;
             bf = f32_above(best_t - tsh);
-            if ((ANY && !PRODUCT && best_ref != REF_NONE) || ovf) running = false;
+            if ((ANY && !PRODUCT && best_ref != REF_NONE) || ovf || zero) running = false;
         }
     }
 
-    // ---- WW_PRODUCT, phase 2: every distinct hit prim counts once per reached leaf that lists it
-    V3 acc = v3(1.0, 1.0, 1.0);   // renderer.rs:211
-    if constexpr (PRODUCT) {
-        const bool root_is_leaf = sc.nodes32[0].aux != 0xFFFFFFFFu;
-        bool zero = false;
-        for (uint32_t h = 0; h < n_hits && !ovf && !zero; ++h) {
-            const int ref = (int)hits[h * RTX_BLOCK];
-            int pid, mat;
-            if (ref >= 0) {
-                const long long ids = __double_as_longlong(reinterpret_cast<const double *>(sc.tris + ref)[9]);   // (prim_id, material)
-                pid = (int)(ids & 0xFFFFFFFFLL);
-                mat = (int)(ids >> 32);
-            } else {
-                pid = sc.spheres[~ref].prim_id;
-                mat = sc.spheres[~ref].material;
-            }
-            uint32_t m = 1u;
-            if (!root_is_leaf) {
-                m = 0u;
-                const int e0 = sc.prim_leaf_begin[pid], e1 = sc.prim_leaf_begin[pid + 1];
-                for (int e = e0; e < e1; ++e) {
-                    const uint32_t leaf = (uint32_t)sc.prim_leaves[e];
-                    const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + leaf);
-                    const float4 qa = nq[0], qb = nq[1];
-                    const float pnx = r.sx ? qa.x : qa.w, pfx = r.sx ? qa.w : qa.x;
-                    const float pny = r.sy ? qa.y : qb.x, pfy = r.sy ? qb.x : qa.y;
-                    const float pnz = r.sz ? qa.z : qb.y, pfz = r.sz ? qb.y : qa.z;
-                    // the box widened by delta missed => the f64 test fails (as the octree walk descends)
-                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(pnx, ix, cnx), 0.0f), fmaf(pny, iy, cny)), fmaf(pnz, iz, cnz));
-                    const float hi = fminf(fminf(fmaf(pfx, ix, cfx), fmaf(pfy, iy, cfy)), fmaf(pfz, iz, cfz));
-                    if (!(lo <= hi)) continue;
-                    // the box shrunk by delta passed => the f64 test passes; in between: the reference's test on the stored box
-                    bool reached = surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
-                                              fmaf(pfz, iz, cnz));
-                    if (!reached) {
-                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + leaf);
-                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
-                        double tn, tf;
-                        reached = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf);
-                    }
-                    m += reached ? 1u : 0u;
-                }
-            }
-            const rtx_material &mt = sc.materials[mat];
-            const V3 tr_ = mt.kind == RTX_MAT_FLAT ? v3(0.0, 0.0, 0.0) : v3(mt.transmission[0], mt.transmission[1], mt.transmission[2]);
-            for (uint32_t k = 0; k < m; ++k) acc = acc * tr_;
-            zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
-        }
-    }
-
+    if constexpr (PRODUCT) count_hits();   // what the lists still hold
     // infinite prims last, in order (octree.rs:163-165,185-186)
     if (active && !ovf) {
         for (int p = 0; p < sc.n_planes; ++p) {
@@ -1645,10 +1645,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
 #define RTX_SHADOW_WAVES 6
 #endif
 #ifndef RTX_PRODUCT_WAVES
-#define RTX_PRODUCT_WAVES 5   // the shadow product walk (scenes with transmissive materials): 96 VGPRs, no spills; heptoroid 1 420 -> 1 371 ms against 6
+#define RTX_PRODUCT_WAVES 5   // the shadow product walk over the octree: 96 VGPRs, no spills; heptoroid 1 420 -> 1 371 ms against 6
+#endif
+#ifndef RTX_PRODUCT_BVH_WAVES
+#define RTX_PRODUCT_BVH_WAVES 4   // the two-phase shadow product: 128 VGPRs, no spills (at 5: 84 B of scratch per lane); heptoroid 703 -> 666 ms
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_FAST || MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES)) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_BVH_WAVES : (MODE == MODE_PRODUCT_FAST ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES))) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
     constexpr bool BVH = MODE == MODE_ANY_BVH || MODE == MODE_PRODUCT_BVH;
     // (MODE_PRODUCT_BVH: the node stack of traverse_bvh, then the level stack of traverse_exact for the feelers handed over)

@@ -172,8 +172,8 @@ typedef struct rtx_options {
      * shard_count == 0 means 1. */
     uint32_t shard_index;
     uint32_t shard_count;
-    uint32_t batch_rays;      /* rays traced per wavefront step (0 = default 8 Mi) */
-    uint32_t pool_rays;       /* capacity of the ray pool in rays (0 = default: 8 x batch) */
+    uint32_t batch_rays;      /* rays traced per wavefront step (0 = default: 8 Mi, fewer when the pool of a deep recursion would exceed a quarter of the free device memory) */
+    uint32_t pool_rays;       /* capacity of the ray pool in rays (0 = default: what the frame and its recursion depth can need at this batch size) */
     uint32_t flags;           /* RTX_FLAG_* */
 } rtx_options;
 

@@ -758,14 +758,30 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if (!base) return fail(RTX_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)herr));
         if ((st = carve_static(base, s->lights.size(), n_samples, need, opt->batch_rays, v, &batch, &pool_cap))) return st;
     } else {
-        if (!batch) {   // default: 8 Mi rays per launch (measured: bunny 10.9 -> 9.9 ms against 4 Mi, sponza within 1 %), shrunk so that
-                        // the pool stays <= 64 Mi rays (5.6 GB)
-            uint64_t b = (64ull << 20) / need.per_batch;
-            batch = (uint32_t)std::min<uint64_t>(8u << 20, std::max<uint64_t>(b, 256u << 10));
+        if (!batch) {   // default: 8 Mi rays per launch (measured: bunny 10.9 -> 9.9 ms against 4 Mi, sponza within 1 %; heptoroid depth 10:
+                        // 664 -> 632 ms against 1.8 Mi), shrunk so that the pool (88 B per ray) stays within a quarter of the device memory
+                        // that is free now (the pool this handle already holds counts as free) and never below 64 Mi rays (5.6 GB)
+            size_t free_b = 0, total_b = 0;
+            HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t room = ((uint64_t)free_b + (uint64_t)w.pool.cap * 88u) / 4u / 88u;
+            const uint64_t cap_rays = std::min<uint64_t>(std::max<uint64_t>(room, 64ull << 20), (1ull << 32) - 1);
+            uint64_t b = cap_rays / need.per_batch;
+            batch = (uint32_t)std::min<uint64_t>(8u << 20, std::max<uint64_t>(b / RTX_BLOCK * RTX_BLOCK, 256u << 10));
         }
         batch = std::max<uint32_t>(batch, RTX_BLOCK);
-        uint64_t pool_cap64 = opt->pool_rays ? opt->pool_rays : (uint64_t)batch * need.per_batch;
-        pool_cap64 = std::max<uint64_t>(pool_cap64, (uint64_t)batch * (1 + fanout));
+        uint64_t pool_cap64 = opt->pool_rays;
+        if (!pool_cap64) {
+            // generation 0 holds at most `batch` rays, generation g > 0 at most batch * fanout (the children of one launch), and no
+            // generation more than every sample's descendants of that depth: a small frame does not reserve a deep pool
+            pool_cap64 = std::min<uint64_t>(batch, n_samples);
+            uint64_t gen = n_samples;
+            for (uint32_t g = 1; g <= need.levels; ++g) {
+                gen = std::min<uint64_t>(gen * fanout, (uint64_t)batch * fanout);
+                pool_cap64 += gen;
+            }
+        }
+        pool_cap64 = std::max<uint64_t>(pool_cap64, (uint64_t)std::min<uint64_t>(batch, std::max<uint32_t>(n_samples, 1u)) * (1 + fanout));
+        pool_cap64 = std::max<uint64_t>(pool_cap64, RTX_BLOCK);
         if (pool_cap64 >= (1ull << 32)) return fail(RTX_ERR_LIMIT, "ray pool above 2^32 rays");
         pool_cap = (uint32_t)pool_cap64;
         if ((st = ensure_work(s, pool_cap, batch, n_samples))) return st;

@@ -2143,7 +2143,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     }
     COOP_FENCE();
 #ifdef RTX_COUNT_LOOPS
-    uint32_t c_steps = 0, c_drain = 0, c_pairs = 0, c_pairlanes = 0;
+    uint32_t c_steps = 0, c_drain = 0, c_pairs = 0, c_pairlanes = 0, c_gsteps = 0, c_devents = 0;
 #endif
     auto run_pairs = [&]() {
         const uint32_t n = pair_n < 64u ? pair_n : 64u;
@@ -2230,6 +2230,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         if (!__any(g_on)) break;
 #ifdef RTX_COUNT_LOOPS
         ++c_steps;
+        c_gsteps += (uint32_t)__popcll(__ballot(g_on)) >> 4;
 #endif
         if (g_on) {
             const bool hasB = nodeB != NONE;
@@ -2283,6 +2284,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         const bool walk_over = (tmask & 0xFFFFu) == 0u && sp == 0u;
         const bool want_x = g_on && (qn >= RTX_COOP_QT || (walk_over && qn > 0u));
         if (__any(want_x)) {
+#ifdef RTX_COUNT_LOOPS
+            ++c_devents;
+#endif
             if constexpr (!MULTI) {
                 // All four queues of the wave are drained together and the (primitive, group) items are dealt out evenly: every
                 // round, each 16-lane row takes ONE item and tests the primitive's box against the 16 rays of the item's group
@@ -2445,10 +2449,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         }
     }
 #ifdef RTX_COUNT_LOOPS
-    if (lane == 0u) {   // per wave: loop steps, drain rounds, run_pairs calls (high 32 bits of [2]: lanes busy in them)
+    if (lane == 0u) {   // per wave: loop steps, drain rounds, run_pairs calls; [0][..]: lanes busy in them, group-steps, steps with a drain
         atomicAdd(&counters->work[1][0], (unsigned long long)c_steps);
         atomicAdd(&counters->work[1][1], (unsigned long long)c_drain);
-        atomicAdd(&counters->work[1][2], (unsigned long long)c_pairs + ((unsigned long long)c_pairlanes << 24));
+        atomicAdd(&counters->work[1][2], (unsigned long long)c_pairs);
+        atomicAdd(&counters->work[0][0], (unsigned long long)c_pairlanes);
+        atomicAdd(&counters->work[0][1], (unsigned long long)c_gsteps);
+        atomicAdd(&counters->work[0][2], (unsigned long long)c_devents);
     }
 #elif defined(RTX_COUNT_WORK)
     if (valid) {

@@ -1214,7 +1214,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     // traverse_bvh's stack entries: node index | quantised entry distance (at least 6 bits of it)
     uint32_t bvh4_bits = 1;
     while ((1ll << bvh4_bits) < wstats.nodes4) ++bvh4_bits;
-    const bool bvh4_ok = bvh4_bits <= 26 && std::getenv("RTX_NO_BVH4") == nullptr;
+    // (traverse_bvh packs a primitive's index into 24 bits of a pair word)
+    const bool bvh4_ok = bvh4_bits <= 26 && d->n_triangles < (1 << 24) && d->n_spheres < (1 << 24) && std::getenv("RTX_NO_BVH4") == nullptr;
     lap("hierarchies (SAH)");
     up.submit(wide, &ds.wide);
     up.submit(bvh4, &ds.bvh4);

@@ -248,9 +248,10 @@ DEV bool plane_hit(const DPlane &pl, const Ray &r, double t_min, double t_max, d
 // MODE_PRODUCT:      shadow feeler with transmissive materials: every candidate of the
 //                    multiset, duplicates included (renderer.rs:209-217), order-free product.
 // MODE_CLOSEST_BVH / MODE_ANY_BVH: MODE_CLOSEST / MODE_ANY over the 4-wide hierarchy instead of the octree (traverse_bvh).
+// MODE_CLOSEST_BVH_DEALT: MODE_CLOSEST_BVH with the exact tests dealt out over the wave (traverse_bvh_dealt): scenes with transmissive materials.
 // MODE_PRODUCT_BVH: MODE_PRODUCT_FAST's answer in two phases: the distinct hit prims over the 4-wide hierarchy, then their multiplicities.
 enum { MODE_CLOSEST = 0, MODE_CLOSEST_REF = 1, MODE_ANY = 2, MODE_PRODUCT = 3, MODE_PRODUCT_FAST = 4, MODE_CLOSEST_BVH = 5, MODE_ANY_BVH = 6,
-       MODE_PRODUCT_BVH = 7 };
+       MODE_PRODUCT_BVH = 7, MODE_CLOSEST_BVH_DEALT = 8 };
 
 struct Hit {
     double t;
@@ -848,13 +849,13 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
 // A lane's list holds RTX_BVH_HITS refs; when one is full the wave runs phase 2 on what all lists hold and goes on.
 // *overflow: the caller must run the all-f64 walk (an infinite inverse direction component, a full stack).
 #ifndef RTX_BVH_HITS
-#define RTX_BVH_HITS 6      // (1 in the forced-failure test build, tests/test_gpu_variants.py: phase 2 after every hit)
+#define RTX_BVH_HITS 8      // (1 in the forced-failure test build, tests/test_gpu_variants.py: phase 2 after every hit, a second hit in a round hands over)
 #endif
 template <int WW>
 DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_stack, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
-                      bool *overflow, uint32_t *s_hits = nullptr, V3 *prod = nullptr) {
-    constexpr bool PRODUCT = WW == WW_PRODUCT;
-    constexpr bool ANY = WW == WW_ANY || PRODUCT;   // the window is [t_lo, t_hi] for every candidate, nothing is culled by a best hit
+                      bool *overflow) {
+    static_assert(WW == WW_CLOSEST || WW == WW_ANY, "the shadow product walks with traverse_bvh_dealt");
+    constexpr bool ANY = WW == WW_ANY;   // the window is [t_lo, t_hi] for every candidate, nothing is culled by a best hit
     uint32_t *stk = s_stack + threadIdx.x;   // stride RTX_BLOCK
     uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
     double best_t = ANY ? t_hi : inf();      // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
@@ -883,64 +884,9 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
 
     uint32_t sp = 0u, cnt = 0u, cur = 0u;
     bool running = active && !re.miss;   // a ray that misses the scene's cube has no finite candidate
-    bool ovf = PRODUCT && active && !finite_dir;   // 0 * inf = NaN slab distances: the all-f64 walk
-    if (ovf) running = false;
+    bool ovf = false;
     bool have_cur = running;             // the root (octree.rs:149,177 never tests the root's box; neither does this walk)
-    uint32_t n_hits = 0u;                // WW_PRODUCT: distinct prims hit so far
-    uint32_t *hits = PRODUCT ? s_hits + threadIdx.x : nullptr;   // stride RTX_BLOCK
     const float INF = __int_as_float(0x7F800000);
-
-    // ---- WW_PRODUCT, phase 2: every distinct hit prim counts once per reached leaf that lists it.  Run by all lanes together, on what
-    // their lists hold: when a lane's list is full (before it would overflow) and after the walk.
-    V3 acc = v3(1.0, 1.0, 1.0);   // renderer.rs:211
-    bool zero = false;            // ... has reached exactly (0,0,0): finite factors, it stays there
-    auto count_hits = [&]() {
-        const bool root_is_leaf = sc.nodes32[0].aux != 0xFFFFFFFFu;
-        for (uint32_t h = 0; h < n_hits && !ovf && !zero; ++h) {
-            const int ref = (int)hits[h * RTX_BLOCK];
-            int pid, mat;
-            if (ref >= 0) {
-                const long long ids = __double_as_longlong(reinterpret_cast<const double *>(sc.tris + ref)[9]);   // (prim_id, material)
-                pid = (int)(ids & 0xFFFFFFFFLL);
-                mat = (int)(ids >> 32);
-            } else {
-                pid = sc.spheres[~ref].prim_id;
-                mat = sc.spheres[~ref].material;
-            }
-            uint32_t m = 1u;
-            if (!root_is_leaf) {
-                m = 0u;
-                const int e0 = sc.prim_leaf_begin[pid], e1 = sc.prim_leaf_begin[pid + 1];
-                for (int e = e0; e < e1; ++e) {
-                    const uint32_t leaf = (uint32_t)sc.prim_leaves[e];
-                    const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + leaf);
-                    const float4 qa = nq[0], qb = nq[1];
-                    const float pnx = r.sx ? qa.x : qa.w, pfx = r.sx ? qa.w : qa.x;
-                    const float pny = r.sy ? qa.y : qb.x, pfy = r.sy ? qb.x : qa.y;
-                    const float pnz = r.sz ? qa.z : qb.y, pfz = r.sz ? qb.y : qa.z;
-                    // the box widened by delta missed => the f64 test fails (as the octree walk descends)
-                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(pnx, ix, cnx), 0.0f), fmaf(pny, iy, cny)), fmaf(pnz, iz, cnz));
-                    const float hi = fminf(fminf(fmaf(pfx, ix, cfx), fmaf(pfy, iy, cfy)), fmaf(pfz, iz, cfz));
-                    if (!(lo <= hi)) continue;
-                    // the box shrunk by delta passed => the f64 test passes; in between: the reference's test on the stored box
-                    bool reached = surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
-                                              fmaf(pfz, iz, cnz));
-                    if (!reached) {
-                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + leaf);
-                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
-                        double tn, tf;
-                        reached = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf);
-                    }
-                    m += reached ? 1u : 0u;
-                }
-            }
-            const rtx_material &mt = sc.materials[mat];
-            const V3 tr_ = mt.kind == RTX_MAT_FLAT ? v3(0.0, 0.0, 0.0) : v3(mt.transmission[0], mt.transmission[1], mt.transmission[2]);
-            for (uint32_t k = 0; k < m; ++k) acc = acc * tr_;
-            zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
-        }
-        n_hits = 0u;
-    };
 
     for (;;) {
         if (!__any(running || cnt > 0u)) break;
@@ -1014,10 +960,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
         const uint32_t holders = (uint32_t)__popcll(__ballot(cnt > 0u));
         if (__any(stalled) || holders >= RTX_BVH_FLUSH || !__any(running)) {
             for (uint32_t i = 0; __any(i < cnt); ++i) {
-                if constexpr (PRODUCT) {
-                    if (__any(n_hits >= RTX_BVH_HITS)) count_hits();   // a round adds at most one hit per lane
-                }
-                if (i < cnt && !(ANY && !PRODUCT && best_ref != REF_NONE) && !ovf && !zero) {   // any-hit: one occluder is enough
+                if (i < cnt && !(ANY && best_ref != REF_NONE) && !ovf) {   // any-hit: one occluder is enough
                     const uint32_t c = cand[i * RTX_BLOCK];
                     const int ref = (int)c >> 1;
                     const bool surely_in = (c & 1u) != 0u;
@@ -1027,9 +970,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                         if (surely_in || tri_bbox_hit(tr, r)) {
                             WORK(++w_prims;)
                             double t, be, ga;
-                            if (PRODUCT) {
-                                if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
-                            } else if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
+                            if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
                             } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
                                 // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
@@ -1044,9 +985,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                         if (surely_in || sphere_bbox_hit(cc, radius, r)) {
                             WORK(++w_prims;)
                             double t;
-                            if (PRODUCT) {
-                                if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) hits[n_hits++ * RTX_BLOCK] = (uint32_t)ref;
-                            } else if (ANY) {
+                            if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
                             } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
                                 best_t = t;
@@ -1058,11 +997,355 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
             }
             cnt = 0u;
             bf = f32_above(best_t - tsh);
-            if ((ANY && !PRODUCT && best_ref != REF_NONE) || ovf || zero) running = false;
+            if ((ANY && best_ref != REF_NONE) || ovf) running = false;
         }
     }
 
+    // infinite prims last, in order (octree.rs:163-165,185-186)
+    if (active && !ovf) {
+        for (int p = 0; p < sc.n_planes; ++p) {
+            const DPlane &pl = sc.planes[p];
+            double t;
+            if (ANY) {
+                if (best_ref == REF_NONE && plane_hit(pl, r, t_lo, t_hi, &t)) best_ref = REF_PLANE | p;
+            } else if (plane_hit(pl, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
+                best_t = t;
+                best_ref = REF_PLANE | p;
+            }
+        }
+    }
+    hit->t = best_t;
+    hit->ref = best_ref;
+    *overflow = ovf;
+    WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
+}
+
+// traverse_bvh_dealt: THE EXACT TESTS ARE DEALT OUT OVER THE WAVE.  In traverse_bvh a lane tests its own parked candidates, and a round of a
+// flush runs as long as the lane with the most candidates has some: measured 18 % of the lanes busy in a round on heptoroid feelers
+// (14 exact tests per feeler), 23 % on its closest-hit rays (11 per ray), 28 % on sponza's (4 per ray).  Here the walk appends (owner
+// lane, primitive) pairs to ONE list per wave (a ballot and a prefix count per child slot), and a round hands 64 pairs to the 64
+// lanes, whoever owns the ray: the tester fetches the owner's ray with ds_bpermute (20 words), runs the reference's tests on it and
+// reports through LDS: closest hit = a 64-bit atomic minimum on the bits of t (t > 0: the order of the bit patterns is the order of the
+// values), then the lowest index among the prims that hold the minimum; any hit = the ref; product = a slot in the owner's hit list,
+// taken with an atomic counter.  95 % of the lanes are busy in a round; the price is 20 more VGPRs (the foreign ray next to the own
+// one: 4 waves per SIMD instead of 5) and a dearer step, so it runs where the exact tests dominate: the shadow product (heptoroid
+// 393 -> 313 ms of shadows per frame) and the closest-hit rays of scenes with transmissive materials, whose rays run along the inside
+// of thin shells (251 -> 235 ms of closest hit + shading); with 1 to 4 exact tests per ray (bunny, sibenik, sponza) it is 2 to 7 % slower.
+// pair word: owner lane << 26 | surely_in << 25 | sphere << 24 | index (the host keeps scenes with 2^24 triangles or spheres off this walk)
+#define RTX_BVH_LIST (RTX_BVH_CAND * 64)   // words in a wave's pair list
+#ifndef RTX_BVH_DEALT_WAVES
+#define RTX_BVH_DEALT_WAVES 5   // k_closest<MODE_CLOSEST_BVH_DEALT>: 96 VGPRs and 40 B of scratch per lane (at 4 waves: 114 VGPRs, no scratch; heptoroid closest + shade 247 against 235 ms)
+#endif
+#ifndef RTX_BVH_ROUND_MIN
+#define RTX_BVH_ROUND_MIN 16u   // closest hit: a round runs once this many pairs wait (heptoroid closest + shade: 16: 233, 32: 235, 64: 238 ms)
+#endif
+template <int WW>
+DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_t *s_stack, uint32_t *s_cand, uint32_t *s_aux, double t_lo, double t_hi,
+                      Hit *hit, bool *overflow, uint32_t *s_hits = nullptr, V3 *prod = nullptr) {
+    constexpr bool PRODUCT = WW == WW_PRODUCT;
+    constexpr bool CLOSEST = WW == WW_CLOSEST;
+    constexpr bool ANY = !CLOSEST;   // the window is [t_lo, t_hi] for every candidate, nothing is culled by a best hit
+    const uint32_t lane = threadIdx.x & 63u, wbase = threadIdx.x & ~63u;
+    uint32_t *stk = s_stack + threadIdx.x;                         // stride RTX_BLOCK
+    uint32_t *list = s_cand + (threadIdx.x >> 6) * RTX_BVH_LIST;   // the wave's pair list
+    // per-lane result words, written by whichever lane tests a pair of this lane's ray:
+    // closest: u64 best[RTX_BLOCK] (bits of t), int ref[RTX_BLOCK]; any: int ref[RTX_BLOCK]; product: u32 n_hits[RTX_BLOCK]
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_aux);
+    int *s_ref = reinterpret_cast<int *>(CLOSEST ? s_aux + 2 * RTX_BLOCK : s_aux);
+    uint32_t *s_nh = s_aux;
+#define BVH_FENCE() asm volatile("" ::: "memory")   /* LDS traffic between lanes of ONE wave: executed in order, only the compiler must not move or cache it */
+    double best_t = ANY ? t_hi : inf();      // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
+    int best_ref = REF_NONE;
+    WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
+    if constexpr (CLOSEST) { s_best[threadIdx.x] = (unsigned long long)__double_as_longlong(inf()); s_ref[threadIdx.x] = -1; }
+    else if constexpr (PRODUCT) s_nh[threadIdx.x] = 0u;
+    else s_ref[threadIdx.x] = REF_NONE;
+    BVH_FENCE();
+
+    const RootEntry re = root_entry(sc, r, r.ox - sc.centre[0], r.oy - sc.centre[1], r.oz - sc.centre[2]);
+    const double tsh = re.t_shift;   // every f32 slab distance below is t - tsh
+    const double orx = r.ox - sc.centre[0] + tsh * r.dx, ory = r.oy - sc.centre[1] + tsh * r.dy, orz = r.oz - sc.centre[2] + tsh * r.dz;
+    const double big = fmax(fmax(fabs(orx), fabs(ory)), fabs(orz)) + sc.radius;
+    const double delta = big * (1.0 / 1048576.0);
+    const float ix = (float)r.ix, iy = (float)r.iy, iz = (float)r.iz;
+    const float hx = f32_above(delta * fabs(r.ix)), hy = f32_above(delta * fabs(r.iy)), hz = f32_above(delta * fabs(r.iz));
+    const float cx = (float)(-(orx * r.ix)), cy = (float)(-(ory * r.iy)), cz = (float)(-(orz * r.iz));
+    const float cnx = cx - hx, cfx = cx + hx, cny = cy - hy, cfy = cy + hy, cnz = cz - hz, cfz = cz + hz;
+    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
+    float bf = f32_above(best_t - tsh);
+    // rows of a DNode4 in 16-byte units: lo.x lo.y lo.z hi.x hi.y hi.z ref
+    const uint32_t onx = r.sx ? 0u : 3u, ofx = r.sx ? 3u : 0u, ony = r.sy ? 1u : 4u, ofy = r.sy ? 4u : 1u, onz = r.sz ? 2u : 5u, ofz = r.sz ? 5u : 2u;
+    // stack entry = node index | quantised entry distance << node_bits; the distance is rounded DOWN (a pop never drops a node that
+    // could still hold the closest hit); every entry distance lies in [0, 4 * big]
+    const uint32_t nbits = sc.bvh4_node_bits, nmask = (1u << nbits) - 1u;
+    const float qmax = (float)((1u << (32u - nbits)) - 1u);
+    const float qscale = qmax / (4.0f * (float)big) * 0.999999f;
+    const float qinv = 4.0f * (float)big / qmax * 0.999999f;
+
+    uint32_t sp = 0u, cur = 0u;
+    uint32_t n_pairs = 0u;               // pairs waiting in the wave's list (wave-uniform)
+#ifdef RTX_COUNT_FLUSH
+    uint32_t f_iters = 0, f_rounds = 0, f_tests = 0;   // experiment: wave-steps, test rounds, pairs tested
+#endif
+    bool running = active && !re.miss;   // a ray that misses the scene's cube has no finite candidate
+    bool ovf = PRODUCT && active && !finite_dir;   // 0 * inf = NaN slab distances: the all-f64 walk
+    if (ovf) running = false;
+    bool have_cur = running;             // the root (octree.rs:149,177 never tests the root's box; neither does this walk)
+    uint32_t *hits = PRODUCT ? s_hits + threadIdx.x : nullptr;   // WW_PRODUCT: the distinct prims hit so far, stride RTX_BLOCK
+    const float INF = __int_as_float(0x7F800000);
+
+    // ---- WW_PRODUCT, phase 2: every distinct hit prim counts once per reached leaf that lists it.  Every lane works through its own
+    // list: when some list is half full (a round may add several hits to one list) and after the walk.
+    V3 acc = v3(1.0, 1.0, 1.0);   // renderer.rs:211
+    bool zero = false;            // ... has reached exactly (0,0,0): finite factors, it stays there
+    auto count_hits = [&]() {
+        const bool root_is_leaf = sc.nodes32[0].aux != 0xFFFFFFFFu;
+        BVH_FENCE();
+        uint32_t n_hits = s_nh[threadIdx.x];
+        if (n_hits > RTX_BVH_HITS) n_hits = RTX_BVH_HITS;   // (hits that found the list full wait in the pair list and are tested again)
+        for (uint32_t h = 0; h < n_hits && !ovf && !zero; ++h) {
+            const int ref = (int)hits[h * RTX_BLOCK];
+            int pid, mat;
+            if (ref >= 0) {
+                const long long ids = __double_as_longlong(reinterpret_cast<const double *>(sc.tris + ref)[9]);   // (prim_id, material)
+                pid = (int)(ids & 0xFFFFFFFFLL);
+                mat = (int)(ids >> 32);
+            } else {
+                pid = sc.spheres[~ref].prim_id;
+                mat = sc.spheres[~ref].material;
+            }
+            uint32_t m = 1u;
+#ifdef RTX_ABL_NOCOUNT
+            if (false) {       // ablation (wrong products): phase 1 alone
+#else
+            if (!root_is_leaf) {
+#endif
+                m = 0u;
+                const int e0 = sc.prim_leaf_begin[pid], e1 = sc.prim_leaf_begin[pid + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const uint32_t leaf = (uint32_t)sc.prim_leaves[e];
+                    const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + leaf);
+                    const float4 qa = nq[0], qb = nq[1];
+                    const float pnx = r.sx ? qa.x : qa.w, pfx = r.sx ? qa.w : qa.x;
+                    const float pny = r.sy ? qa.y : qb.x, pfy = r.sy ? qb.x : qa.y;
+                    const float pnz = r.sz ? qa.z : qb.y, pfz = r.sz ? qb.y : qa.z;
+                    // the box widened by delta missed => the f64 test fails (as the octree walk descends)
+                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(pnx, ix, cnx), 0.0f), fmaf(pny, iy, cny)), fmaf(pnz, iz, cnz));
+                    const float hi = fminf(fminf(fmaf(pfx, ix, cfx), fmaf(pfy, iy, cfy)), fmaf(pfz, iz, cfz));
+                    if (!(lo <= hi)) continue;
+                    // the box shrunk by delta passed => the f64 test passes; in between: the reference's test on the stored box
+                    bool reached = surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
+                                              fmaf(pfz, iz, cnz));
+                    if (!reached) {
+                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + leaf);
+                        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                        double tn, tf;
+                        reached = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf);
+                    }
+                    m += reached ? 1u : 0u;
+                }
+            }
+            const rtx_material &mt = sc.materials[mat];
+            const V3 tr_ = mt.kind == RTX_MAT_FLAT ? v3(0.0, 0.0, 0.0) : v3(mt.transmission[0], mt.transmission[1], mt.transmission[2]);
+            for (uint32_t k = 0; k < m; ++k) acc = acc * tr_;
+            zero = acc.x == 0.0 && acc.y == 0.0 && acc.z == 0.0;   // finite factors: it stays exactly 0
+        }
+        if (zero) running = false;
+        s_nh[threadIdx.x] = 0u;
+        BVH_FENCE();
+    };
+
+    // ---- one round of exact tests: up to 64 waiting pairs, one per lane.  Must be called by all 64 lanes.
+    auto test_round = [&]() {
+        if constexpr (PRODUCT) {
+            BVH_FENCE();
+            if (__any(s_nh[threadIdx.x] > RTX_BVH_HITS / 2u)) count_hits();
+        }
+        const uint32_t take = n_pairs < 64u ? n_pairs : 64u;
+        n_pairs -= take;
+        const bool mine = lane < take;
+#ifdef RTX_COUNT_FLUSH
+        ++f_rounds;
+        if (mine) ++f_tests;
+#endif
+        BVH_FENCE();
+        const uint32_t pw = list[n_pairs + (mine ? lane : 0u)];
+        const int ol = (int)(pw >> 26);          // the owner's lane in the wave
+        const uint32_t ot = wbase + (uint32_t)ol;   // ... and in the workgroup
+        Ray q;                                   // the owner's ray (ray.rs:23-42: the same bits, fetched instead of rebuilt)
+        q.ox = __shfl(r.ox, ol); q.oy = __shfl(r.oy, ol); q.oz = __shfl(r.oz, ol);
+        q.dx = __shfl(r.dx, ol); q.dy = __shfl(r.dy, ol); q.dz = __shfl(r.dz, ol);
+        q.ix = __shfl(r.ix, ol); q.iy = __shfl(r.iy, ol); q.iz = __shfl(r.iz, ol);   // (rebuilt with three divisions where needed: no faster)
+        q.sx = q.ix > 0.0; q.sy = q.iy > 0.0; q.sz = q.iz > 0.0;
+        q.flip = 0u;                             // (the octree walks' child order: not read here)
+        const double q_hi = ANY ? __shfl(t_hi, ol) : inf();
+        bool run = mine;
+        if constexpr (ANY && !PRODUCT) run = run && s_ref[ot] == REF_NONE;   // any-hit: one occluder is enough
+        bool found = false;
+        double t = 0.0;
+        const bool surely_in = (pw & (1u << 25)) != 0u;
+        const uint32_t idx = pw & 0x00FFFFFFu;
+        const int ref = (pw & (1u << 24)) ? ~(int)idx : (int)idx;
+        if (run) {
+            if (ref >= 0) {
+                int pid, mat;
+                TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                if (surely_in || tri_bbox_hit(tr, q)) {
+                    WORK(++w_prims;)
+                    double be, ga;
+                    // closest hit: prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55) is a running
+                    // minimum over the candidates with t > t_min: the window's upper end only rejects what the minimum rejects
+                    found = tri_hit(tr, q, t_lo, q_hi, &t, &be, &ga);     // any hit / product: renderer.rs:212, t in [EPSILON, distance_to_light]
+                }
+            } else {
+                const DSphere &sp_ = sc.spheres[~ref];
+                V3 cc = v3(sp_.c[0], sp_.c[1], sp_.c[2]);
+                double radius = sp_.r;
+                if (surely_in || sphere_bbox_hit(cc, radius, q)) {
+                    WORK(++w_prims;)
+                    found = sphere_hit(cc, radius, q, t_lo, q_hi, &t);
+                }
+            }
+        }
+        if constexpr (CLOSEST) {
+            // s_ref holds the winner as (sphere << 24 | index), 0xFFFFFFFF = none.  Prims that tie at exactly the same t (a ray through
+            // the shared edge of two axis-aligned triangles): the lowest index wins, whichever round or lane tests it; ray.rs:52-60
+            // keeps the first it visits, which for prims listed in one leaf is the one inserted first = the lowest index
+            found = found && t > t_lo;
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+            uint32_t *s_key = reinterpret_cast<uint32_t *>(s_ref);
+            const unsigned long long before = s_best[ot];
+            if (found) atomicMin(&s_best[ot], tb);
+            BVH_FENCE();
+            const bool wins = found && s_best[ot] == tb;
+            if (wins && tb < before) s_key[ot] = 0xFFFFFFFFu;   // a new minimum: the old winner goes (every lane that ties writes the same)
+            BVH_FENCE();
+            if (wins) atomicMin(&s_key[ot], pw & 0x01FFFFFFu);
+        } else if constexpr (PRODUCT) {
+            // a hit that finds its owner's list full (more than RTX_BVH_HITS / 2 hits of one feeler in one round) goes back into the
+            // pair list: the next round starts with phase 2 on the full list, then the pair is tested again and fits
+            bool again = false;
+            if (found) {
+                const uint32_t slot = atomicAdd(&s_nh[ot], 1u);
+                if (slot < RTX_BVH_HITS) s_hits[slot * RTX_BLOCK + ot] = (uint32_t)ref;
+                else again = true;
+            }
+            const unsigned long long am = __ballot(again);
+            if (am != 0ull) {
+                if (again) list[n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u))] = pw;
+                n_pairs += (uint32_t)__popcll(am);
+            }
+        } else {
+            if (found) s_ref[ot] = ref;
+        }
+        BVH_FENCE();
+    };
+
+    for (;;) {
+        for (int step = 0; step < RTX_BVH_STEPS; ++step) {
+            if (n_pairs > RTX_BVH_LIST - 4u * 64u || !__any(running)) break;   // (wave-uniform) room for one more step of every lane
+#ifdef RTX_COUNT_FLUSH
+            if (lane == 0u) ++f_iters;
+#endif
+            bool visit = running;
+            if (visit && !have_cur) {
+                if (sp == 0u) { running = false; visit = false; }
+                else {
+                    --sp;
+                    const uint32_t e = stk[sp * RTX_BLOCK];
+                    if (CLOSEST && (float)(e >> nbits) * qinv > bf) visit = false;   // it starts behind the best hit
+                    else cur = e & nmask;
+                }
+            }
+            bool push[4] = {false, false, false, false};
+            uint32_t word[4] = {0u, 0u, 0u, 0u};
+            if (visit) {
+                have_cur = false;
+                WORK(++w_nodes;)
+                const float4 *nq = reinterpret_cast<const float4 *>(sc.bvh4 + cur);
+                const float4 pnx = nq[onx], pny = nq[ony], pnz = nq[onz], pfx = nq[ofx], pfy = nq[ofy], pfz = nq[ofz];
+                const uint4 rf = reinterpret_cast<const uint4 *>(nq)[6];
+                const float nxs[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, nys[4] = {pny.x, pny.y, pny.z, pny.w}, nzs[4] = {pnz.x, pnz.y, pnz.z, pnz.w};
+                const float fxs[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, fys[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, fzs[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
+                const uint32_t refs[4] = {rf.x, rf.y, rf.z, rf.w};
+                float key[4];   // entry distance of a node child that is hit, else +inf
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // (an empty slot's box is (+inf, -inf): lo > hi or NaN, never hit)
+                    const float lo = fmaxf(fmaxf(fmaxf(fmaf(nxs[c], ix, cnx), 0.0f), fmaf(nys[c], iy, cny)), fmaf(nzs[c], iz, cnz));
+                    const float hi = fminf(fminf(fminf(fmaf(fxs[c], ix, cfx), bf), fmaf(fys[c], iy, cfy)), fmaf(fzs[c], iz, cfz));
+                    const bool hit_c = lo <= hi;
+                    const uint32_t kind = refs[c] & RTX_WREF_KIND;
+                    key[c] = (hit_c && kind == RTX_WREF_NODE) ? lo : INF;
+                    if (hit_c && (kind == RTX_WREF_TRI || kind == RTX_WREF_SPHERE)) {
+                        WORK(++w_entries;)
+                        // the box shrunk by delta instead of widened: a ray through it passes the exact f64 entry test (octree.rs:170)
+                        // with a margin far above f64 rounding, so that test can be skipped
+                        bool surely_in = false;
+                        if (finite_dir) {
+                            const float li = fmaxf(fmaxf(fmaf(nxs[c], ix, cfx), fmaf(nys[c], iy, cfy)), fmaf(nzs[c], iz, cfz));
+                            const float hi2 = fminf(fminf(fmaf(fxs[c], ix, cnx), fmaf(fys[c], iy, cny)), fmaf(fzs[c], iz, cnz));
+                            surely_in = li <= hi2 && hi2 > 0.0f;
+                        }
+                        push[c] = true;
+                        word[c] = (lane << 26) | (surely_in ? (1u << 25) : 0u) | (kind == RTX_WREF_SPHERE ? (1u << 24) : 0u) | (refs[c] & 0x00FFFFFFu);
+                    }
+                }
+                // the nearest node child is visited next, the others are pushed (in slot order)
+                int near = 0;
+                float knear = key[0];
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (key[c] < knear) { knear = key[c]; near = c; }
+                if (knear < INF) {
+                    have_cur = true;
+                    cur = (near == 0 ? refs[0] : (near == 1 ? refs[1] : (near == 2 ? refs[2] : refs[3]))) & RTX_WREF_INDEX;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c != near && key[c] < INF) {
+                            if (sp < RTX_BVH_STACK) {
+                                const uint32_t q = ANY ? 0u : (uint32_t)fminf(key[c] * qscale, qmax);
+                                stk[sp * RTX_BLOCK] = (refs[c] & RTX_WREF_INDEX) | (q << nbits);
+                                ++sp;
+                            } else {
+                                ovf = true;
+                            }
+                        }
+                    }
+                    if (ovf) { running = false; have_cur = false; }
+                }
+            }
+            // the candidates of this step join the wave's list
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned long long pm = __ballot(push[c]);
+                if (push[c]) list[n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))] = word[c];
+                n_pairs += (uint32_t)__popcll(pm);
+            }
+        }
+        // ---- the exact tests: full rounds as soon as they can be had (closest hit: sooner, a best t found early culls nodes), the rest
+        // once no lane walks any more
+        const bool over = !__any(running);
+        while (n_pairs >= (CLOSEST ? RTX_BVH_ROUND_MIN : 64u) || (over && n_pairs > 0u)) test_round();
+        BVH_FENCE();
+        if constexpr (CLOSEST) {
+            best_t = __longlong_as_double((long long)s_best[threadIdx.x]);
+            bf = f32_above(best_t - tsh);
+        } else if constexpr (!PRODUCT) {
+            if (s_ref[threadIdx.x] != REF_NONE) running = false;   // any-hit: one occluder is enough
+        }
+        if (over) break;
+    }
+
     if constexpr (PRODUCT) count_hits();   // what the lists still hold
+    if constexpr (CLOSEST) {
+        BVH_FENCE();
+        const uint32_t kw = (uint32_t)s_ref[threadIdx.x];
+        best_ref = kw == 0xFFFFFFFFu ? REF_NONE : ((kw & (1u << 24)) ? ~(int)(kw & 0x00FFFFFFu) : (int)kw);
+    } else if constexpr (!PRODUCT) {
+        BVH_FENCE();
+        best_ref = s_ref[threadIdx.x];
+    }
     // infinite prims last, in order (octree.rs:163-165,185-186)
     if (active && !ovf) {
         for (int p = 0; p < sc.n_planes; ++p) {
@@ -1087,6 +1370,10 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
     *overflow = ovf;
     if (PRODUCT) *prod = acc;
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
+#ifdef RTX_COUNT_FLUSH   // (with RTX_COUNT_WORK) experiment: wave-steps and test rounds instead of lane-steps and entries
+    hit->w_nodes = f_iters; hit->w_entries = lane == 0u ? f_rounds : 0u; hit->w_prims = f_tests;
+#endif
+#undef BVH_FENCE
 }
 
 template <int MODE>
@@ -1325,11 +1612,13 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 #define RTX_CLOSEST_WAVES 6
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_WAVES : RTX_CLOSEST_WAVES) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
+__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_WAVES : (MODE == MODE_CLOSEST_BVH_DEALT ? RTX_BVH_DEALT_WAVES : RTX_CLOSEST_WAVES)) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
                                                                           DCounters *counters, double *hit_t, int32_t *hit_ref) {
-    __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (MODE == MODE_CLOSEST_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
-    if constexpr (MODE != MODE_CLOSEST_BVH) init_lds(s_stk);
+    constexpr bool BVH = MODE == MODE_CLOSEST_BVH || MODE == MODE_CLOSEST_BVH_DEALT;
+    __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 3 * RTX_BLOCK : 2];   // traverse_bvh_dealt: best t (u64) and ref per lane
+    if constexpr (!BVH) init_lds(s_stk);
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
     uint32_t slot = begin + (valid ? gid : 0u);
@@ -1365,6 +1654,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
         bool ovf;
         traverse_bvh<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit, &ovf);
         if (degen || ovf) hit.ref = REF_RETRY;                          // (a full stack: the all-f64 walk answers the ray)
+    } else if constexpr (MODE == MODE_CLOSEST_BVH_DEALT) {
+        size_t cap = pool.cap;
+        const double *f = pool.f + slot;
+        Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
+                      : make_ray(v3(0, 0, 0), v3(0, 0, 1));
+        const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
+        bool ovf;
+        traverse_bvh_dealt<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, s_aux, T_MIN, inf(), &hit, &ovf);
+        if (degen || ovf) hit.ref = REF_RETRY;
     } else if (valid) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
@@ -1654,10 +1952,10 @@ template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_BVH_WAVES : (MODE == MODE_PRODUCT_FAST ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES))) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                                                        uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
     constexpr bool BVH = MODE == MODE_ANY_BVH || MODE == MODE_PRODUCT_BVH;
-    // (MODE_PRODUCT_BVH: the node stack of traverse_bvh, then the level stack of traverse_exact for the feelers handed over)
-    __shared__ uint32_t s_stk[BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
     __shared__ uint32_t s_hits[MODE == MODE_PRODUCT_BVH ? RTX_BVH_HITS * RTX_BLOCK : 1];
+    __shared__ uint32_t s_aux[MODE == MODE_PRODUCT_BVH ? RTX_BLOCK : 1];   // traverse_bvh_dealt: the length of the hit list, per lane
     if constexpr (!BVH) init_lds(s_stk);
     uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     const uint32_t tries_shift = (uint32_t)__ffs((int)tries) - 1u;   // (no 64-bit division for the usual try counts)
@@ -1716,11 +2014,23 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
         Hit hit;
         V3 pr = v3(0, 0, 0);
         bool fb = false;
-        traverse_bvh<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, EPSILON, distance_to_light, &hit, &fb, s_hits, &pr);
+        traverse_bvh_dealt<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, s_aux, EPSILON, distance_to_light, &hit, &fb, s_hits, &pr);
         if (valid) v = pr;
-        if (valid && fb) {   // axis-parallel feeler, more distinct hit prims than the list holds, a full stack: the all-f64 restatement
-            Hit h2;
-            traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, distance_to_light, &h2, &v);
+#ifdef RTX_COUNT_FB
+        {   // experiment: how many feelers (and waves) hand over to the all-f64 walk
+            const unsigned long long vb = __ballot(valid), fbb = __ballot(valid && fb);
+            if ((threadIdx.x & 63u) == 0u) {
+                atomicAdd(&counters->work[0][0], (unsigned long long)__popcll(vb));
+                atomicAdd(&counters->work[0][1], (unsigned long long)__popcll(fbb));
+                atomicAdd(&counters->work[0][2], fbb ? 1ull : 0ull);
+                atomicAdd(&counters->work[1][0], 1ull);
+            }
+        }
+#endif
+        if (valid && fb) {   // axis-parallel feeler or a full stack: the all-f64 restatement answers it (k_shadow_retry: its share of the
+                             // group's average is added there, the sum over the tries is linear)
+            v = v3(0.0, 0.0, 0.0);
+            retry_append(sq, light, (uint32_t)gid, sample, counters);
         }
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {
@@ -2190,6 +2500,23 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
                 WORK(++w_prims;)
                 double t, be, ga;
                 occluded = tri_hit(tr, q, EPSILON, q_dist, &t, &be, &ga);
+#ifdef RTX_COUNT_CLASS
+                {   // experiment: how the exact tests end (0 hit; 1 barycentrics out by > 1e-3; 2 out by less; 3 |t| < 1e-9; 4 behind; 5 beyond the light)
+                    double t2, b2, g2;
+                    int cls;
+                    if (occluded) cls = 0;
+                    else {
+                        const bool any = tri_hit(tr, q, -inf(), inf(), &t2, &b2, &g2);
+                        if (!any) {
+                            V3 dd = v3(q.dx, q.dy, q.dz), e1 = tr.v1 - tr.v0, e2 = tr.v2 - tr.v0, pp = cross(dd, e2), ss = v3(q.ox, q.oy, q.oz) - tr.v0;
+                            const double det = dot(e1, pp), idt = 1.0 / det, bb = idt * dot(ss, pp), gg = idt * dot(dd, cross(ss, e1));
+                            const double out = fmax(fmax(-bb, -gg), bb + gg - 1.0);
+                            cls = out > 1.0e-3 ? 1 : 2;
+                        } else cls = fabs(t2) < 1.0e-9 ? 3 : (t2 < 0.0 ? 4 : 5);
+                    }
+                    atomicAdd(&counters->work[cls / 3][cls % 3], 1ull);
+                }
+#endif
             } else {
                 const DSphere &sp_ = sc.spheres[idx];
                 WORK(++w_prims;)
@@ -2520,14 +2847,20 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_resolve(DFrame fr, const double *
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, const double *origin, const double *direction,
                                                         int32_t *prim_id, double *t_out) {
-    // (MODE_CLOSEST_BVH: the node stack of traverse_bvh, then the level stack of traverse_exact for the rays handed over)
-    __shared__ uint32_t s_stk[MODE == MODE_CLOSEST_BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
-    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (MODE == MODE_CLOSEST_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
-    if constexpr (MODE != MODE_CLOSEST_BVH) init_lds(s_stk);
+    // (BVH: the node stack of traverse_bvh, then the level stack of traverse_exact for the rays handed over)
+    constexpr bool BVH = MODE == MODE_CLOSEST_BVH || MODE == MODE_CLOSEST_BVH_DEALT;
+    __shared__ uint32_t s_stk[BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
+    __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
+    __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 3 * RTX_BLOCK : 2];
+    if constexpr (!BVH) init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (gid >= n) return;    // lanes that leave here simply drop out of the wave-wide votes below
-    V3 o = v3(origin[gid * 3], origin[gid * 3 + 1], origin[gid * 3 + 2]);
-    V3 d = v3(direction[gid * 3], direction[gid * 3 + 1], direction[gid * 3 + 2]);
+    // MODE_CLOSEST_BVH_DEALT: every lane of the wave takes part in the walk (its exact tests are dealt out over the wave's 64 lanes); in
+    // the other modes lanes that leave here simply drop out of the wave-wide votes
+    if (MODE != MODE_CLOSEST_BVH_DEALT && gid >= n) return;
+    const bool act = gid < n;
+    const int64_t g = act ? gid : 0;
+    V3 o = v3(origin[g * 3], origin[g * 3 + 1], origin[g * 3 + 2]);
+    V3 d = v3(direction[g * 3], direction[g * 3 + 1], direction[g * 3 + 2]);
     Ray r = make_ray(o, d);
     Hit hit;
     V3 unused;
@@ -2540,6 +2873,12 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
         bool ovf;
         traverse_bvh<WW_CLOSEST>(sc, r, !degen, s_stk, s_cand, T_MIN, inf(), &hit, &ovf);
         if (degen || ovf) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+    } else if constexpr (MODE == MODE_CLOSEST_BVH_DEALT) {   // what k_closest<MODE_CLOSEST_BVH_DEALT> + k_closest_retry do
+        const bool degen = degenerate_dir(r.dx, r.dy, r.dz);
+        bool ovf;
+        traverse_bvh_dealt<WW_CLOSEST>(sc, r, act && !degen, s_stk, s_cand, s_aux, T_MIN, inf(), &hit, &ovf);
+        if (act && (degen || ovf)) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+        if (!act) return;
     } else {
         traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     }
@@ -2558,6 +2897,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_
     __shared__ uint32_t s_stk[MODE == MODE_PRODUCT_BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_PRODUCT_FAST ? RTX_CAND_WORDS : (MODE == MODE_PRODUCT_BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
     __shared__ uint32_t s_hits[MODE == MODE_PRODUCT_BVH ? RTX_BVH_HITS * RTX_BLOCK : 1];
+    __shared__ uint32_t s_aux[MODE == MODE_PRODUCT_BVH ? RTX_BLOCK : 1];
     if constexpr (MODE != MODE_PRODUCT_BVH) init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (MODE != MODE_PRODUCT_FAST && MODE != MODE_PRODUCT_BVH && gid >= n) return;
@@ -2572,7 +2912,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shadow_products(DScene sc, int64_
     V3 v = v3(0, 0, 0);
     if constexpr (MODE == MODE_PRODUCT_BVH) {   // what k_shadow<MODE_PRODUCT_BVH> runs per feeler
         bool fb = false;
-        traverse_bvh<WW_PRODUCT>(sc, r, act, s_stk, s_cand, EPSILON, dist, &hit, &fb, s_hits, &v);
+        traverse_bvh_dealt<WW_PRODUCT>(sc, r, act, s_stk, s_cand, s_aux, EPSILON, dist, &hit, &fb, s_hits, &v);
         if (act && fb) traverse_exact<MODE_PRODUCT>(sc, r, s_stk + threadIdx.x, EPSILON, dist, &hit, &v);
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {   // what k_shadow<MODE_PRODUCT_FAST> runs per feeler
         bool fb = false;
@@ -2643,7 +2983,12 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                            count, counters, hit_t, hit_ref);
     else
     {
-        if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK))
+        // (scenes with transmissive materials: rays run along the inside of thin shells and meet ten candidates each: the exact tests dealt
+        // out over the wave, see traverse_bvh_dealt)
+        if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK) && !sc.all_opaque)
+            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH_DEALT>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                               count, counters, hit_t, hit_ref);
+        else if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK))
             hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
                                count, counters, hit_t, hit_ref);
         else
@@ -2671,8 +3016,10 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // wide (a ground plane seen near the horizon) and walk most of the hierarchy
     const bool exact = (fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) != 0u;   // re-render after a retry-list overflow
     const bool coop = sc.all_opaque && sc.wide && !(fr.flags & RTX_FLAG_NO_COOP) && !exact;
-    const bool any_hit = sc.all_opaque != 0 && !exact;   // the any-hit kernels hand degenerate feelers to k_shadow_retry
-    const bool bvh = sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK);   // per-lane any-hit walks over the 4-wide hierarchy
+    const bool bvh = sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK);   // per-lane walks over the 4-wide hierarchy
+    const bool product_bvh = !sc.all_opaque && !exact && !(fr.flags & RTX_FLAG_REFERENCE_ORDER) && bvh && sc.prim_leaves;
+    // the any-hit kernels hand degenerate feelers to k_shadow_retry, the two-phase product those it cannot answer
+    const bool any_hit = (sc.all_opaque != 0 && !exact) || product_bvh;
     if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap), 0, sizeof(uint32_t), (hipStream_t)stream);
     if (exact)   // the all-f64 product walk answers every feeler, degenerate or not (all-opaque scenes: a product of zeros)
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
@@ -2700,7 +3047,7 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
-    else if (bvh && sc.prim_leaves)   // the distinct hit prims over the 4-wide hierarchy, then their multiplicities
+    else if (product_bvh)   // the distinct hit prims over the 4-wide hierarchy, then their multiplicities
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     else
@@ -2820,6 +3167,9 @@ void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double
     if (flags & RTX_FLAG_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_nearest<MODE_CLOSEST_REF>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n,
                            origin, direction, prim_id, t_out);
+    else if (sc.bvh4 && !(flags & RTX_FLAG_OCTREE_WALK) && !sc.all_opaque)   // (the walk the frames of this scene take, as in rtxk_trace)
+        hipLaunchKernelGGL(k_nearest<MODE_CLOSEST_BVH_DEALT>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n, origin,
+                           direction, prim_id, t_out);
     else if (sc.bvh4 && !(flags & RTX_FLAG_OCTREE_WALK))
         hipLaunchKernelGGL(k_nearest<MODE_CLOSEST_BVH>, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, n, origin,
                            direction, prim_id, t_out);

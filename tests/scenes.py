@@ -183,7 +183,7 @@ def kitchen_sink_scene(rtx, lights="mixed"):
     return b.build(), cam
 
 
-def axis_aligned_scene(rtx):
+def axis_aligned_scene(rtx, transmissive=False):
     """Everything on integer coordinates and aligned with the axes: a tessellated floor, two boxes, a point light and a camera
     that looks straight down from above the centre.  With an odd image width the centre column of primary rays has a direction
     component that is exactly zero and origins on octree planes; its hit points share a coordinate with the light, so their
@@ -192,7 +192,9 @@ def axis_aligned_scene(rtx):
     b.point_light((0, 6, 1), (1.0, 0.9, 0.8))
     b.sphere_light((2, 7, 0), (0.3, 0.3, 0.5), 1.0)
     floor = b.cook_torrance(k_a=0.1, k_d=0.6, k_s=0.4, k_sg=0.4, gauss_constant=5.0, roughness=0.1, ior=1.3, diffuse=(0.7, 0.7, 0.7))
-    box = b.cook_torrance(k_a=0.1, k_d=0.7, k_s=0.3, k_sg=0.2, gauss_constant=5.0, roughness=0.2, ior=1.3, diffuse=(0.8, 0.3, 0.2))
+    # transmissive: the boxes let light through (shadow product instead of any-hit, the closest-hit walk with dealt exact tests)
+    box = b.cook_torrance(k_a=0.1, k_d=0.7, k_s=0.3, k_sg=0.2, gauss_constant=5.0, roughness=0.2, ior=1.3, diffuse=(0.8, 0.3, 0.2),
+                          **(dict(k_tg=0.5, transmission=(0.8, 0.6, 0.4)) if transmissive else {}))
     tris = []
     for i in range(-4, 4):
         for j in range(-4, 4):

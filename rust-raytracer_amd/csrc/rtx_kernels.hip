@@ -2016,17 +2016,6 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
         bool fb = false;
         traverse_bvh_dealt<WW_PRODUCT>(sc, r, valid, s_stk, s_cand, s_aux, EPSILON, distance_to_light, &hit, &fb, s_hits, &pr);
         if (valid) v = pr;
-#ifdef RTX_COUNT_FB
-        {   // experiment: how many feelers (and waves) hand over to the all-f64 walk
-            const unsigned long long vb = __ballot(valid), fbb = __ballot(valid && fb);
-            if ((threadIdx.x & 63u) == 0u) {
-                atomicAdd(&counters->work[0][0], (unsigned long long)__popcll(vb));
-                atomicAdd(&counters->work[0][1], (unsigned long long)__popcll(fbb));
-                atomicAdd(&counters->work[0][2], fbb ? 1ull : 0ull);
-                atomicAdd(&counters->work[1][0], 1ull);
-            }
-        }
-#endif
         if (valid && fb) {   // axis-parallel feeler or a full stack: the all-f64 restatement answers it (k_shadow_retry: its share of the
                              // group's average is added there, the sum over the tries is linear)
             v = v3(0.0, 0.0, 0.0);

@@ -805,8 +805,10 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
 
     // the depth test at the top of Renderer::trace (renderer.rs:106): no rays at all
     bool trace_anything = opt->reflect_depth > 0 && opt->refract_depth > 0 && fr.spp > 0;
-    // the any-hit shadow kernels keep a retry list per launch; its overflow flag is read once, after the last launch
-    const bool uses_retry = trace_anything && opt->shadow_samples > 0 && !s->lights.empty() && s->d.all_opaque &&
+    // the any-hit shadow kernels and the two-phase shadow product keep a retry list per launch (rtxk_shadow); its overflow flag is read
+    // once, after the last launch
+    const bool product_bvh = !s->d.all_opaque && s->d.bvh4 && s->d.prim_leaves && !(fr.flags & (RTX_FLAG_OCTREE_WALK | RTX_FLAG_REFERENCE_ORDER));
+    const bool uses_retry = trace_anything && opt->shadow_samples > 0 && !s->lights.empty() && (s->d.all_opaque || product_bvh) &&
                             !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS);
 
     if (n_samples) HIPCHECK(hipMemsetAsync(v.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));

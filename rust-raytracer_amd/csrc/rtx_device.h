@@ -179,7 +179,9 @@ struct DShadowQ {
     uint32_t cap;
     uint32_t retry_cap; // pairs per light (RTX_RETRY_CAP in the library's own workspace, smaller in the static one)
 };
-#define RTX_RETRY_CAP (1u << 20)
+#ifndef RTX_RETRY_CAP
+#define RTX_RETRY_CAP (1u << 20)   // (2^14 in the forced-failure test build librtx_smallstack.so: a 1.5 M-sample frame overflows it)
+#endif
 // internal bit of DFrame.flags (never accepted from rtx_options.flags): every shadow launch runs the all-f64 restatement of the
 // reference's walk (k_shadow<MODE_PRODUCT>), which is valid for every feeler of every scene.  Set for the re-render of a frame
 // whose retry list overflowed (more degenerate feelers in one launch than the list holds).

@@ -9,9 +9,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = {
-    # traverse_bvh with a 3-entry stack and a 1-entry list of distinct hit prims: most rays overflow them and are answered by the
-    # all-f64 walks (k_closest_retry, the shadow retry list, traverse_exact<MODE_PRODUCT>) -- the hand-offs of a full stack / list
-    "librtx_smallstack.so": "-DRTX_BVH_STACK=3 -DRTX_BVH_HITS=1",
+    # traverse_bvh / traverse_bvh_dealt with a 3-entry stack: most closest-hit rays and many feelers overflow it and are answered by the all-f64 walks
+    # (k_closest_retry, the shadow retry list of the any-hit walk and of the two-phase product; the build's retry lists hold 2^14
+    # feelers instead of 2^20, so a 1.5 M-sample frame overflows them and is rendered again with exact shadows); a 1-entry list of distinct hit prims: phase 2 after every hit, and a second
+    # hit of a feeler in one round waits in the pair list and is tested again
+    "librtx_smallstack.so": "-DRTX_BVH_STACK=3 -DRTX_BVH_HITS=1 -DRTX_RETRY_CAP=16384u",
     # k_shadow_coop: every 7th tentative hit fails its deferred f64 entry-bbox confirmation and the feeler goes to the retry list
     "librtx_failconfirm.so": "-DRTX_DEBUG_FAIL_CONFIRM=7",
 }

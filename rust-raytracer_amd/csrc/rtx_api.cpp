@@ -531,10 +531,12 @@ void free_work(Work &w) {
     if (w.sq.key) hipFree(w.sq.key);
     if (w.sq.sample) hipFree(w.sq.sample);
     if (w.sq.retry) hipFree(w.sq.retry);
+    if (w.sq.wide) hipFree(w.sq.wide);
     if (w.sq2.f) hipFree(w.sq2.f);
     if (w.sq2.key) hipFree(w.sq2.key);
     if (w.sq2.sample) hipFree(w.sq2.sample);
     if (w.sq2.retry) hipFree(w.sq2.retry);
+    if (w.sq2.wide) hipFree(w.sq2.wide);
     for (hipStream_t a : w.aux)
         if (a) hipStreamDestroy(a);
     if (w.d_counters) hipFree(w.d_counters);
@@ -564,22 +566,24 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     }
     size_t nl = std::max<size_t>(s->lights.size(), 1);
     if (w.sq.cap < batch) {
-        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); uint32_t *keep = w.sq.retry; w.sq = DShadowQ(); w.sq.retry = keep; }
+        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); hipFree(w.sq.wide); uint32_t *keep = w.sq.retry; w.sq = DShadowQ(); w.sq.retry = keep; }
         w.sq.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.key, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.sample, nl * (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq.wide, nl * (1u + (size_t)batch)))) return st;
         if (!w.sq.retry && (st = dev_alloc(&w.sq.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         w.sq.cap = batch;
     }
     if (w.sq2.cap < batch) {
-        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); uint32_t *keep = w.sq2.retry; w.sq2 = DShadowQ(); w.sq2.retry = keep; }
+        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); hipFree(w.sq2.wide); uint32_t *keep = w.sq2.retry; w.sq2 = DShadowQ(); w.sq2.retry = keep; }
         w.sq2.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq2.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.key, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.sample, nl * (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq2.wide, nl * (1u + (size_t)batch)))) return st;
         if (!w.sq2.retry && (st = dev_alloc(&w.sq2.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         w.sq2.cap = batch;
     }
@@ -664,14 +668,15 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t fixed = up(sizeof(DCounters)) + up(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)) +
                          up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 16 * 256 /* alignment of the arrays below */;
-    // per ray of a batch: hit record 12, pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8
+    // per ray of a batch: hit record 12, pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
+    // one entry per light in the list of groups left to the per-lane shadow kernel 4
     const size_t pool_per = std::max<uint64_t>(need.per_batch, 1 + (uint64_t)need.fanout);
-    const size_t per = 12 + pool_per * 88 + nl * 60 + nl * 8;
-    if (fixed + per * RTX_BLOCK + nl * 8 > RTX_STATIC_SCRATCH_BYTES)
+    const size_t per = 12 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4;
+    if (fixed + per * RTX_BLOCK + nl * 8 + nl * 256 > RTX_STATIC_SCRATCH_BYTES)
         return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: this call needs " + std::to_string(fixed + per * RTX_BLOCK) +
                                        " bytes of workspace, the static device scratch holds " + std::to_string(RTX_STATIC_SCRATCH_BYTES) +
                                        " (render fewer samples per call: shard_index / shard_count, or use rtx_render_device)");
-    uint64_t batch = (RTX_STATIC_SCRATCH_BYTES - fixed - nl * 8) / per;
+    uint64_t batch = (RTX_STATIC_SCRATCH_BYTES - fixed - nl * 8 - nl * 256) / per;
     batch = std::min<uint64_t>(batch, want_batch ? want_batch : (1u << 20));
     batch = std::max<uint64_t>(RTX_BLOCK, batch / RTX_BLOCK * RTX_BLOCK);
     const uint64_t pool_cap = batch * pool_per;
@@ -692,6 +697,7 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     v.sq.sample = (uint32_t *)take(nl * batch * sizeof(uint32_t));
     v.sq.retry_cap = (uint32_t)batch;
     v.sq.retry = (uint32_t *)take(nl * (2 + 2 * batch) * sizeof(uint32_t));
+    v.sq.wide = (uint32_t *)take(nl * (1 + batch) * sizeof(uint32_t));
     v.sq.cap = (uint32_t)batch;
     v.sq2 = v.sq;   // one launch after the other on the caller's stream: one queue is enough
     if ((size_t)(p - base) > RTX_STATIC_SCRATCH_BYTES) return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: workspace layout exceeds the static scratch");

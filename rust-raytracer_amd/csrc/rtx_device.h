@@ -176,6 +176,7 @@ struct DShadowQ {
     uint32_t *sample;   // [n_lights][cap]
     uint32_t *retry;    // [n_lights][2 + 2 * retry_cap]: count, pad, then (feeler index, primary sample) pairs: the degenerate feelers
                         // of the light's launch, answered by k_shadow_retry with the all-f64 walk
+    uint32_t *wide;     // [n_lights][1 + cap]: count, then the queue groups k_shadow_coop<MULTI> leaves to the per-lane kernel that follows it
     uint32_t cap;
     uint32_t retry_cap; // pairs per light (RTX_RETRY_CAP in the library's own workspace, smaller in the static one)
 };

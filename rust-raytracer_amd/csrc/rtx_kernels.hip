@@ -1950,7 +1950,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_BVH_WAVES : (MODE == MODE_PRODUCT_FAST ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES))) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
-                                                       uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc) {
+                                                       uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc,
+                                                       const uint32_t *group_list) {
+    // group_list != nullptr: the launch works through a list of queue groups (what k_shadow_coop<MULTI> left over: count, then the
+    // groups) instead of the whole queue; the grid is sized for the whole queue and blocks past the list's end leave at once
     constexpr bool BVH = MODE == MODE_ANY_BVH || MODE == MODE_PRODUCT_BVH;
     __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
@@ -1962,6 +1965,13 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
     uint32_t group = pow2_tries ? (uint32_t)(gid >> tries_shift) : (uint32_t)(gid / tries);
     uint32_t k = pow2_tries ? ((uint32_t)gid & (tries - 1u)) : (uint32_t)(gid % tries);
     bool valid = group < n_groups;
+    if (group_list) {
+        const uint32_t n_list = group_list[0];
+        if ((uint64_t)blockIdx.x * RTX_BLOCK >= (uint64_t)n_list * tries) return;   // (the whole workgroup)
+        valid = group < n_list;
+        group = valid ? group_list[1u + group] : 0u;
+    }
+    const uint32_t feeler = group * tries + k;   // its index in the launch's queue (retry list entries)
     size_t qc = sq.cap;
     V3 hp = v3(0, 0, 0), w = v3(0, 0, 0);
     uint64_t key = 0;
@@ -1999,7 +2009,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
         const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_shadow_retry; counts as 0 here
         traverse_ww<WW_ANY>(sc, r, valid && !degen, s_stk, s_cand, EPSILON, distance_to_light, &hit);
         if (valid) v = (hit.ref == REF_NONE && !degen) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
-        if (degen) retry_append(sq, light, (uint32_t)gid, sample, counters);
+        if (degen) retry_append(sq, light, feeler, sample, counters);
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_ANY_BVH) {
         Hit hit;
@@ -2008,7 +2018,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
         traverse_bvh<WW_ANY>(sc, r, valid && !degen, s_stk, s_cand, EPSILON, distance_to_light, &hit, &ovf);
         const bool retry = degen || (valid && ovf);                     // (a full stack: the all-f64 walk answers the feeler)
         if (valid) v = (hit.ref == REF_NONE && !retry) ? v3(1.0, 1.0, 1.0) : v3(0.0, 0.0, 0.0);
-        if (retry) retry_append(sq, light, (uint32_t)gid, sample, counters);
+        if (retry) retry_append(sq, light, feeler, sample, counters);
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_PRODUCT_BVH) {
         Hit hit;
@@ -2019,7 +2029,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
         if (valid && fb) {   // axis-parallel feeler or a full stack: the all-f64 restatement answers it (k_shadow_retry: its share of the
                              // group's average is added there, the sum over the tries is linear)
             v = v3(0.0, 0.0, 0.0);
-            retry_append(sq, light, (uint32_t)gid, sample, counters);
+            retry_append(sq, light, feeler, sample, counters);
         }
         WORK(count_work(valid, hit, counters->work[1]);)
     } else if constexpr (MODE == MODE_PRODUCT_FAST) {
@@ -2328,6 +2338,18 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         wide = !beam_ok || spread > RTX_COOP_WIDE * (float)sc.radius;
     }
     if (degen && !wide) retry_append(sq, light, (uint32_t)gid, sample, counters);   // (a wide group is left to k_shadow<MODE_ANY>, which appends)
+    if constexpr (MULTI) {   // the queue groups of a wide unit go on the list of the per-lane kernel that runs next: one atomic per wave
+        uint32_t *wl = sq.wide + (size_t)light * (1u + qc);
+        const bool app = valid && wide && k == 0u;
+        const unsigned long long am = __ballot(app);
+        if (am != 0ull) {
+            const int leader = __ffsll((long long)am) - 1;
+            uint32_t base = 0u;
+            if ((int)lane == leader) base = atomicAdd(wl, (uint32_t)__popcll(am));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (app) wl[1u + base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = group;
+        }
+    }
     // 1 / |d0| from the f32 inverse direction (relative error < 2^-22.4): the slopes are widened by 4e-7 of their size, which
     // covers it, their rounding to f32 and the widening's own rounding
     const double inv0 = (double)fabsf(a0 == 0 ? ix : (a0 == 1 ? iy : iz));
@@ -3012,36 +3034,37 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap), 0, sizeof(uint32_t), (hipStream_t)stream);
     if (exact)   // the all-f64 product walk answers every feeler, degenerate or not (all-opaque scenes: a product of zeros)
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+                           n_groups, tries, pow2, counters, acc, nullptr);
     else if (coop && tries % 16u == 0u) {        // the 16 lanes of a group = feelers of one hit point
         hipLaunchKernelGGL(k_shadow_coop<false>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
     } else if (coop && (tries == 4u || tries == 8u)) {   // measured: with 1 try per hit point (16 origins per group) the per-lane walk wins
-        // groups of 16 / tries neighbouring hit points: the cooperative kernel takes the compact ones and marks their
-        // queue entries empty, the per-lane kernel takes what is left
+        // groups of 16 / tries neighbouring hit points: the cooperative kernel takes the compact ones and lists the others
+        // (sq.wide) for the per-lane kernel, which works through that list in full waves
+        (void)hipMemsetAsync(sq.wide + (size_t)light * (1u + (size_t)sq.cap), 0, sizeof(uint32_t), (hipStream_t)stream);
         hipLaunchKernelGGL(k_shadow_coop<true>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
         if (bvh)
             hipLaunchKernelGGL(k_shadow<MODE_ANY_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                               n_groups, tries, pow2, counters, acc);
+                               n_groups, tries, pow2, counters, acc, sq.wide + (size_t)light * (1u + (size_t)sq.cap));
         else
             hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                               n_groups, tries, pow2, counters, acc);
+                               n_groups, tries, pow2, counters, acc, sq.wide + (size_t)light * (1u + (size_t)sq.cap));
     } else if (sc.all_opaque && bvh)
         hipLaunchKernelGGL(k_shadow<MODE_ANY_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+                           n_groups, tries, pow2, counters, acc, nullptr);
     else if (sc.all_opaque)
         hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+                           n_groups, tries, pow2, counters, acc, nullptr);
     else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+                           n_groups, tries, pow2, counters, acc, nullptr);
     else if (product_bvh)   // the distinct hit prims over the 4-wide hierarchy, then their multiplicities
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+                           n_groups, tries, pow2, counters, acc, nullptr);
     else
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_FAST>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+                           n_groups, tries, pow2, counters, acc, nullptr);
     if (any_hit)
         hipLaunchKernelGGL(k_shadow_retry, dim3(64), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, tries, acc);
 }

@@ -171,11 +171,15 @@ enum { RAY_PRIMARY = 0, RAY_REFLECT = 1, RAY_GLOSS = 2, RAY_REFRACT = 3, RAY_SHA
 // Shadow groups: one entry per (closest hit, light); the shadow kernel gives each of the
 // light's `tries` feelers its own lane.  f holds 6 planes per light: hit position, weight.
 struct DShadowQ {
+    // COMPACT: k_shade writes a group per ray that hit something, in ray order without gaps (k_group_rank / k_group_base), so the
+    // shadow launches run full waves whatever share of the rays left the scene (bunny: half of them); the grid is sized for every
+    // ray of the step and blocks past `*count` leave at once
     double *f;          // [n_lights][6][cap]
     uint64_t *key;      // [n_lights][cap]
     uint32_t *sample;   // [n_lights][cap]
     uint32_t *retry;    // [n_lights][2 + 2 * retry_cap]: count, pad, then (feeler index, primary sample) pairs: the degenerate feelers
                         // of the light's launch, answered by k_shadow_retry with the all-f64 walk
+    uint32_t *count;    // one word: the groups of the step (the same for every light: a ray that hits emits one per light)
     uint32_t *wide;     // [n_lights][1 + cap]: count, then the queue groups k_shadow_coop<MULTI> leaves to the per-lane kernel that follows it
     uint32_t cap;
     uint32_t retry_cap; // pairs per light (RTX_RETRY_CAP in the library's own workspace, smaller in the static one)
@@ -218,7 +222,8 @@ typedef void *rtx_stream_t;
 void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count);
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
-                void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */);
+                void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */,
+                uint32_t *group_rank /* [count] */, uint32_t *group_base /* [2 * ceil(count / RTX_BLOCK)] */);
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);

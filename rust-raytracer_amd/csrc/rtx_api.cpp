@@ -398,7 +398,7 @@ struct Work {
     unsigned long long (*h_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr; // pinned
     double *hit_t = nullptr;
     int32_t *hit_ref = nullptr;
-    uint32_t *group_rank = nullptr, *group_base = nullptr;   // slots of the compact shadow queue (rtxk_trace)
+    uint32_t *group_base = nullptr;   // workgroup counts and bases of the compact shadow queue (rtxk_trace)
     uint32_t hit_cap = 0;
     double *acc = nullptr;
     size_t acc_cap = 0;       // samples
@@ -546,7 +546,6 @@ void free_work(Work &w) {
     if (w.d_ray_slots) hipFree(w.d_ray_slots);
     if (w.hit_t) hipFree(w.hit_t);
     if (w.hit_ref) hipFree(w.hit_ref);
-    if (w.group_rank) hipFree(w.group_rank);
     if (w.group_base) hipFree(w.group_base);
     if (w.h_ray_slots) hipHostFree(w.h_ray_slots);
     if (w.h_up) hipHostFree(w.h_up);
@@ -597,10 +596,10 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     for (hipStream_t &a : w.aux)
         if (!a) HIPCHECK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     if (w.hit_cap < batch) {
-        if (w.hit_t) { hipFree(w.hit_t); hipFree(w.hit_ref); hipFree(w.group_rank); hipFree(w.group_base); w.hit_t = nullptr; w.hit_ref = nullptr; w.group_rank = w.group_base = nullptr; w.hit_cap = 0; }
+        if (w.hit_t) { hipFree(w.hit_t); hipFree(w.hit_ref); hipFree(w.group_base); w.hit_t = nullptr; w.hit_ref = nullptr; w.group_base = nullptr; w.hit_cap = 0; }
         rtx_status st;
         if ((st = dev_alloc(&w.hit_t, batch)) || (st = dev_alloc(&w.hit_ref, batch))) return st;
-        if ((st = dev_alloc(&w.group_rank, batch)) || (st = dev_alloc(&w.group_base, 2 * ((size_t)batch / RTX_BLOCK + 2)))) return st;
+        if ((st = dev_alloc(&w.group_base, 2 * ((size_t)batch / RTX_BLOCK + 2)))) return st;
         w.hit_cap = batch;
     }
     if (!w.d_counters) {
@@ -655,7 +654,7 @@ struct WorkView {
     unsigned long long (*d_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr;
     double *hit_t = nullptr;
     int32_t *hit_ref = nullptr;
-    uint32_t *group_rank = nullptr, *group_base = nullptr;
+    uint32_t *group_base = nullptr;
     double *acc = nullptr;
 };
 
@@ -677,10 +676,10 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t fixed = up(sizeof(DCounters)) + up(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)) +
                          up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 21 * 256 /* alignment of the arrays below */;
-    // per ray of a batch: hit record 12 + queue slot 4 (+ 8 per workgroup), pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
+    // per ray of a batch: hit record 12 (+ 8 per workgroup for the queue slots), pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
     // one entry per light in the list of groups left to the per-lane shadow kernel 4
     const size_t pool_per = std::max<uint64_t>(need.per_batch, 1 + (uint64_t)need.fanout);
-    const size_t per = 12 + 5 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4;
+    const size_t per = 12 + 1 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4;
     if (fixed + per * RTX_BLOCK + nl * 8 + nl * 256 > RTX_STATIC_SCRATCH_BYTES)
         return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: this call needs " + std::to_string(fixed + per * RTX_BLOCK) +
                                        " bytes of workspace, the static device scratch holds " + std::to_string(RTX_STATIC_SCRATCH_BYTES) +
@@ -696,7 +695,6 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     v.acc = (double *)take((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double));
     v.hit_t = (double *)take(batch * sizeof(double));
     v.hit_ref = (int32_t *)take(batch * sizeof(int32_t));
-    v.group_rank = (uint32_t *)take(batch * sizeof(uint32_t));
     v.group_base = (uint32_t *)take(2 * (batch / RTX_BLOCK + 2) * sizeof(uint32_t));
     v.pool.f = (double *)take(pool_cap * 9 * sizeof(double));
     v.pool.key = (uint64_t *)take(pool_cap * sizeof(uint64_t));
@@ -804,7 +802,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         pool_cap = (uint32_t)pool_cap64;
         if ((st = ensure_work(s, pool_cap, batch, n_samples))) return st;
         v.pool = w.pool; v.sq = w.sq; v.sq2 = w.sq2; v.d_counters = w.d_counters; v.d_ray_slots = w.d_ray_slots;
-        v.hit_t = w.hit_t; v.hit_ref = w.hit_ref; v.acc = w.acc; v.group_rank = w.group_rank; v.group_base = w.group_base;
+        v.hit_t = w.hit_t; v.hit_ref = w.hit_ref; v.acc = w.acc; v.group_base = w.group_base;
     }
 
     size_t ev_used = 0;
@@ -909,7 +907,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         }
         const DShadowQ &sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
-                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, v.group_rank, v.group_base);
+                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, v.group_base);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));

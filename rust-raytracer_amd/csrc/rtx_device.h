@@ -171,7 +171,7 @@ enum { RAY_PRIMARY = 0, RAY_REFLECT = 1, RAY_GLOSS = 2, RAY_REFRACT = 3, RAY_SHA
 // Shadow groups: one entry per (closest hit, light); the shadow kernel gives each of the
 // light's `tries` feelers its own lane.  f holds 6 planes per light: hit position, weight.
 struct DShadowQ {
-    // COMPACT: k_shade writes a group per ray that hit something, in ray order without gaps (k_group_rank / k_group_base), so the
+    // COMPACT: k_shade writes a group per ray that hit something, in ray order without gaps (k_closest_retry / k_group_base), so the
     // shadow launches run full waves whatever share of the rays left the scene (bunny: half of them); the grid is sized for every
     // ray of the step and blocks past `*count` leave at once
     double *f;          // [n_lights][6][cap]
@@ -223,7 +223,7 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */,
-                uint32_t *group_rank /* [count] */, uint32_t *group_base /* [2 * ceil(count / RTX_BLOCK)] */);
+                uint32_t *group_base /* [2 * ceil(count / RTX_BLOCK)]: workgroup counts, then their exclusive scan */);
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);

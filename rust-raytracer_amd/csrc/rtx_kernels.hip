@@ -1679,7 +1679,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
 
 // The all-f64 walk in the reference's visitation order for the rays k_closest<MODE_CLOSEST> has marked REF_RETRY (degenerate_dir).
 __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool pool, uint32_t begin, uint32_t count, double *hit_t,
-                                                             int32_t *hit_ref, uint32_t *rank, uint32_t *block_count) {
+                                                             int32_t *hit_ref, uint32_t *block_count) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
     __shared__ uint32_t s_w[RTX_BLOCK / 64];
     const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -1699,19 +1699,13 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool po
             ref = hit.ref;
         }
     }
-    // this pass sees every ray's final hit: the slots of the compact shadow queue (as k_group_rank, which runs where this kernel does not)
-    if (!rank) return;
+    // this pass sees every ray's final hit: the workgroup's number of rays that hit something, for the compact shadow queue (as
+    // k_group_count, which runs where this kernel does not)
+    if (!block_count) return;
     const unsigned long long m = __ballot(ref != REF_NONE);
     if (lane == 0u) s_w[wid] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t before = 0u, total = 0u;
-#pragma unroll
-    for (uint32_t wv = 0; wv < RTX_BLOCK / 64; ++wv) {
-        before += wv < wid ? s_w[wv] : 0u;
-        total += s_w[wv];
-    }
-    if (gid < count) rank[gid] = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (threadIdx.x == 0u) block_count[blockIdx.x] = total;
+    if (threadIdx.x == 0u) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // A degenerate shadow feeler (degenerate_dir) is left out of the any-hit kernels' sums and appended to the launch's retry list:
@@ -1753,23 +1747,17 @@ DEV uint32_t block_alloc(uint32_t c, uint32_t *counter, uint32_t *s_tmp /* >= 6 
 }
 
 // The slots of the compact shadow queue, in RAY order (groups appended in the order workgroups happen to finish would scatter
-// neighbouring screen tiles over the queue: measured, sibenik shadows 6.7 -> 7.2 ms): every ray's rank among the rays of its workgroup
-// that hit something, the workgroup's count, then (k_group_base, one workgroup) the exclusive scan of the counts and the total.
-__global__ void __launch_bounds__(RTX_BLOCK) k_group_rank(const int32_t *hit_ref, uint32_t count, uint32_t *rank, uint32_t *block_count) {
+// neighbouring screen tiles over the queue: measured, sibenik shadows 6.7 -> 7.2 ms): the number of rays of each workgroup that hit
+// something (k_closest_retry, or this kernel where that one does not run), the exclusive scan of these counts and their total
+// (k_group_base); k_shade adds the ray's rank within its workgroup.
+static_assert(RTX_BLOCK == 256, "the workgroup counts are summed over four waves");
+__global__ void __launch_bounds__(RTX_BLOCK) k_group_count(const int32_t *hit_ref, uint32_t count, uint32_t *block_count) {
     __shared__ uint32_t s_w[RTX_BLOCK / 64];
     const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const bool hit = gid < count && hit_ref[gid] != REF_NONE;
-    const unsigned long long m = __ballot(hit);
+    const unsigned long long m = __ballot(gid < count && hit_ref[gid] != REF_NONE);
     if (lane == 0u) s_w[wid] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t before = 0u, total = 0u;
-#pragma unroll
-    for (uint32_t wv = 0; wv < RTX_BLOCK / 64; ++wv) {
-        before += wv < wid ? s_w[wv] : 0u;
-        total += s_w[wv];
-    }
-    if (gid < count) rank[gid] = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (threadIdx.x == 0u) block_count[blockIdx.x] = total;
+    if (threadIdx.x == 0u) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 // One workgroup per 1024 counts, every load coalesced: a workgroup first sums the counts before its segment (at most 31 loads per
 // thread), then scans its own.  (One workgroup whose threads each walked 32 consecutive counts touched a cache line per lane and load:
@@ -1804,7 +1792,7 @@ __global__ void __launch_bounds__(1024) k_group_base(const uint32_t *block_count
 
 // K3 (+K5) shade_and_spawn: the body of Renderer::trace after the closest-hit search
 // (renderer.rs:108-144): local shading per light -> one shadow group per (ray that hit, light), in ray order without gaps
-// (k_group_rank / k_group_base give every ray its slot);
+// (k_closest_retry / k_group_base give every ray its slot);
 // reflection / gloss / transmission children -> ray pool; miss -> skybox / background.
 #define SHADOW_GROUP_EMPTY 0xFFFFFFFFu
 #ifndef RTX_SHADE_WAVES
@@ -1823,7 +1811,7 @@ __global__ void __launch_bounds__(1024) k_group_base(const uint32_t *block_count
 template <bool GENERAL>
 __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHADE_WAVES_LEAN) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                      const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
-                                                     double *acc, int32_t *prim_id_out, const uint32_t *group_rank, const uint32_t *group_base) {
+                                                     double *acc, int32_t *prim_id_out, const uint32_t *group_base) {
     __shared__ uint32_t s_tmp[8];
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool in_range = gid < count;
@@ -1849,10 +1837,18 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
         hit.t = hit_t[gid];
         hit.ref = hit_ref[gid];
     }
-    // the ray's shadow groups (one per light, all at the same index) in the compact queue: k_closest_retry / k_group_base.  Fetched
-    // here, with the ray: next to the stores that need it, it would be one more round trip at 2 waves per SIMD
+    // the ray's shadow groups (one per light, all at the same index) in the compact queue: k_closest_retry / k_group_base
     uint32_t gslot = 0u;
-    if (valid && fr.shadow_samples != 0u && sc.n_lights > 0) gslot = group_base[blockIdx.x] + group_rank[gid];
+    if (fr.shadow_samples != 0u && sc.n_lights > 0) {   // base of the workgroup + rank among its rays that hit (a ballot, one barrier)
+        const uint32_t ln = threadIdx.x & 63u, wv_ = threadIdx.x >> 6;
+        const unsigned long long hm = __ballot(valid && hit.ref != REF_NONE);
+        if (ln == 0u) s_tmp[wv_] = (uint32_t)__popcll(hm);
+        __syncthreads();
+        uint32_t before = group_base[blockIdx.x];
+        for (uint32_t q = 0; q < wv_; ++q) before += s_tmp[q];
+        gslot = before + (uint32_t)__popcll(hm & ((1ull << ln) - 1ull));
+        __syncthreads();   // (s_tmp is used again by block_alloc)
+    }
     uint32_t reflect_depth = (flags >> RAYF_REFLECT_SHIFT) & RAYF_DEPTH_MASK;
     uint32_t refract_depth = (flags >> RAYF_REFRACT_SHIFT) & RAYF_DEPTH_MASK;
     bool inside = (flags & RAYF_INSIDE) != 0u;
@@ -3061,14 +3057,14 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 }
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
-                void *wait_before_shade, void *wait_before_shade2, uint32_t *group_rank, uint32_t *group_base) {
+                void *wait_before_shade, void *wait_before_shade2, uint32_t *group_base) {
     if (count == 0) return;
     const bool want_groups = fr.shadow_samples != 0u && sc.n_lights > 0;   // the slots of the compact shadow queue
     const unsigned nb = grid_for(count);
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
                            count, counters, hit_t, hit_ref);
-        if (want_groups) hipLaunchKernelGGL(k_group_rank, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, hit_ref, count, group_rank, group_base);
+        if (want_groups) hipLaunchKernelGGL(k_group_count, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, hit_ref, count, group_base);
     } else
     {
         // (scenes with transmissive materials: rays run along the inside of thin shells and meet ten candidates each: the exact tests dealt
@@ -3083,7 +3079,7 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
             hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
                                counters, hit_t, hit_ref);
         hipLaunchKernelGGL(k_closest_retry, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
-                           hit_ref, want_groups ? group_rank : nullptr, group_base);
+                           hit_ref, want_groups ? group_base : nullptr);
     }
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
@@ -3091,10 +3087,10 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
         hipLaunchKernelGGL(k_group_base, dim3((nb + 1023u) / 1024u), dim3(1024), 0, (hipStream_t)stream, group_base, nb, group_base + nb, sq.count);
     if (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE))
         hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
-                           hit_ref, sq, counters, acc, prim_id_out, group_rank, group_base + grid_for(count));
+                           hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));
     else
         hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
-                           hit_ref, sq, counters, acc, prim_id_out, group_rank, group_base + grid_for(count));
+                           hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));
 }
 void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc) {

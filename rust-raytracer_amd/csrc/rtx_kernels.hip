@@ -1759,15 +1759,15 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_group_count(const int32_t *hit_re
     __syncthreads();
     if (threadIdx.x == 0u) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-// One workgroup per 1024 counts, every load coalesced: a workgroup first sums the counts before its segment (at most 31 loads per
-// thread), then scans its own.  (One workgroup whose threads each walked 32 consecutive counts touched a cache line per lane and load:
-// 17 us on one CU.)
-__global__ void __launch_bounds__(1024) k_group_base(const uint32_t *block_count, uint32_t n_blocks, uint32_t *block_base, uint32_t *total_out) {
-    __shared__ uint32_t s_pre[16], s_wave[16];
+// One workgroup per 256 counts, every load coalesced: a workgroup first sums the counts before its segment, then scans its own.
+// (One workgroup whose threads each walked 32 consecutive counts touched a cache line per lane and load: 17 us on one CU.  Workgroups
+// of 1024 threads waited 0.35 ms per launch for a CU with 16 free wave slots while shadow launches filled the chip.)
+__global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_count, uint32_t n_blocks, uint32_t *block_base, uint32_t *total_out) {
+    __shared__ uint32_t s_pre[RTX_BLOCK / 64], s_wave[RTX_BLOCK / 64];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t seg0 = blockIdx.x * 1024u, i = seg0 + threadIdx.x;
+    const uint32_t seg0 = blockIdx.x * RTX_BLOCK, i = seg0 + threadIdx.x;
     uint32_t pre = 0u;
-    for (uint32_t j = threadIdx.x; j < seg0; j += 1024u) pre += block_count[j];
+    for (uint32_t j = threadIdx.x; j < seg0; j += RTX_BLOCK) pre += block_count[j];
     const uint32_t c = i < n_blocks ? block_count[i] : 0u;
     uint32_t x = c;   // inclusive scan over the wave
 #pragma unroll
@@ -1782,7 +1782,7 @@ __global__ void __launch_bounds__(1024) k_group_base(const uint32_t *block_count
     __syncthreads();
     uint32_t before = 0u, total = 0u;
 #pragma unroll
-    for (uint32_t wv = 0; wv < 16u; ++wv) {
+    for (uint32_t wv = 0; wv < RTX_BLOCK / 64; ++wv) {
         before += s_pre[wv] + (wv < wid ? s_wave[wv] : 0u);
         total += s_pre[wv] + s_wave[wv];
     }
@@ -3084,7 +3084,7 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
     if (want_groups)   // (after the waits: it writes the queue's group count)
-        hipLaunchKernelGGL(k_group_base, dim3((nb + 1023u) / 1024u), dim3(1024), 0, (hipStream_t)stream, group_base, nb, group_base + nb, sq.count);
+        hipLaunchKernelGGL(k_group_base, dim3(grid_for(nb)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, group_base, nb, group_base + nb, sq.count);
     if (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE))
         hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
                            hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));

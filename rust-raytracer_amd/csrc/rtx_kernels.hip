@@ -2273,8 +2273,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     __shared__ double s_ray[3][RTX_BLOCK];      // direction per lane (the inverse is recomputed where an exact entry-bbox test needs it)
     // every lane's f32 traversal constants, read by whichever lanes test a queued primitive's box against this lane's ray:
     // (ix, iy, iz, tmax_own | cnx, cny, cnz, cfx) + (cfy, cfz)
-    __shared__ float4 s_rayf[2][MULTI ? 1 : RTX_BLOCK];   // MULTI drains row by row, every lane its own ray
-    __shared__ float2 s_rayg[MULTI ? 1 : RTX_BLOCK];
+    __shared__ float4 s_rayf[2][RTX_BLOCK];
+    __shared__ float2 s_rayg[RTX_BLOCK];
     __shared__ double s_org[3][MULTI ? RTX_BLOCK : RTX_BLOCK / 16];   // origin: per group (one hit point), or per lane
     // each group's beam (11 floats), re-read at every node step: they would otherwise sit in registers during the
     // exact tests, where the pressure peaks, and be spilled to scratch memory
@@ -2355,7 +2355,6 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
         const float cx = (float)(-(orx * (double)ix)), cy = (float)(-(ory * (double)iy)), cz = (float)(-(orz * (double)iz));
         cnx = cx - hx; cfx = cx + hx; cny = cy - hy; cfy = cy + hy; cnz = cz - hz; cfz = cz + hz;
     }
-    const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     const float tmax_own = f32_above(distance_to_light - tsh);
     // a feeler that misses the scene's cube (or ends before reaching it) has no finite candidate: it takes no
     // part in the beam and in the per-ray tests
@@ -2527,11 +2526,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     if (MULTI) { s_org[0][threadIdx.x] = r.ox; s_org[1][threadIdx.x] = r.oy; s_org[2][threadIdx.x] = r.oz; }
     else if (l16 == 0u) { s_org[0][sub] = r.ox; s_org[1][sub] = r.oy; s_org[2][sub] = r.oz; }
     s_ray[0][threadIdx.x] = r.dx; s_ray[1][threadIdx.x] = r.dy; s_ray[2][threadIdx.x] = r.dz;
-    if constexpr (!MULTI) {
-        s_rayf[0][threadIdx.x] = make_float4(ix, iy, iz, tmax_own);
-        s_rayf[1][threadIdx.x] = make_float4(cnx, cny, cnz, cfx);
-        s_rayg[threadIdx.x] = make_float2(cfy, cfz);
-    }
+    s_rayf[0][threadIdx.x] = make_float4(ix, iy, iz, tmax_own);
+    s_rayf[1][threadIdx.x] = make_float4(cnx, cny, cnz, cfx);
+    s_rayg[threadIdx.x] = make_float2(cfy, cfz);
     COOP_FENCE();
 #ifdef RTX_COUNT_LOOPS
     uint32_t c_steps = 0, c_drain = 0, c_pairs = 0, c_pairlanes = 0, c_gsteps = 0, c_devents = 0;
@@ -2695,7 +2692,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
 #ifdef RTX_COUNT_LOOPS
             ++c_devents;
 #endif
-            if constexpr (!MULTI) {
+            {
                 // All four queues of the wave are drained together and the (primitive, group) items are dealt out evenly: every
                 // round, each 16-lane row takes ONE item and tests the primitive's box against the 16 rays of the item's group
                 // (their f32 constants come from LDS).  Row-bound draining (each row its own queue) ran max(queue length)
@@ -2759,49 +2756,6 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
                     }
                 }
                 qn = 0u;
-            } else {
-                // groups of several hit points: every row drains its own queue, each lane against its own ray (constants in
-                // registers; the per-lane copies in LDS would cost this variant its fifth workgroup per CU)
-                while (__any(qn > 0u)) {
-                    bool push = false;
-                    uint32_t pref = 0u, powner = lane;
-                    if (qn > 0u) {
-                        --qn;
-                        COOP_FENCE();
-                        const uint32_t c = COOP_QUE(qn);
-                        if (seek) {
-                            const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
-                            const float4 c_lo = pc[0], c_hi = pc[1];
-                            const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
-                            WORK(++w_entries;)
-                            const float enx = sx ? lx : ux, efx = sx ? ux : lx;
-                            const float eny = sy ? ly : uy, efy = sy ? uy : ly;
-                            const float enz = sz ? lz : uz, efz = sz ? uz : lz;
-                            const float lo = fmaxf(fmaxf(fmaxf(fmaf(enx, ix, cnx), 0.0f), fmaf(eny, iy, cny)), fmaf(enz, iz, cnz));
-                            const float hi = fminf(fminf(fminf(fmaf(efx, ix, cfx), tmax_own), fmaf(efy, iy, cfy)), fmaf(efz, iz, cfz));
-                            if (lo <= hi) {
-                                // the box shrunk by delta instead of widened: a ray through it passes the exact f64
-                                // entry test (octree.rs:170) with a margin far above f64 rounding
-                                bool surely_in = false;
-                                if (finite_dir) {
-                                    const float li = fmaxf(fmaxf(fmaf(enx, ix, cfx), fmaf(eny, iy, cfy)), fmaf(enz, iz, cfz));
-                                    const float hi2 = fminf(fminf(fmaf(efx, ix, cnx), fmaf(efy, iy, cny)), fmaf(efz, iz, cnz));
-                                    surely_in = li <= hi2 && hi2 > 0.0f;
-                                }
-                                push = true;
-                                pref = __float_as_uint(c_hi.z);
-                                powner = lane | (surely_in ? 64u : 0u);
-                            }
-                        }
-                    }
-                    const unsigned long long pm = __ballot(push);
-                    if (pm != 0ull) {
-                        if (push) s_pair[wid][pair_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = pair_pack(pref, powner);
-                        pair_n += (uint32_t)__popcll(pm);
-                        COOP_FENCE();
-                        if (pair_n >= 64u) run_pairs();
-                    }
-                }
             }
             if (pair_n >= RTX_COOP_PT) run_pairs();
             a16 = (uint32_t)(__ballot(seek) >> gbase) & 0xFFFFu;

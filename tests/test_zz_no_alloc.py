@@ -41,6 +41,8 @@ def test_noalloc_entry_point_matches_render_device(rtx):
     # second call, smaller input, other kernels (per-lane shadows, 1 spp), same scratch
     small = rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=1, pixel_samples=1, rng_mode=1, seed=9)
     _both(rtx, torch, sc, cam_fn(64, 40), small)
+    # 4 tries: groups of neighbouring hit points in the cooperative kernel, its left-over list and the per-lane kernel, all in the scratch
+    _both(rtx, torch, sc, cam_fn(128, 80), rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=2, rng_mode=1, seed=7))
     sc.close()
     # another handle (transmissive materials: the product walk, two child rays per hit) on the same GPU's scratch
     flat2, cam_fn2 = scenes.mesh_scene(rtx, n_u=24, n_v=16, transmissive=True, point_light=True)

@@ -924,7 +924,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                 for (size_t a = 0; a < n_aux; ++a) HIPCHECK(hipStreamWaitEvent(w.aux[a], ev_back, 0));
             }
         }
-        // shadow groups sit at their ray's index (empty where the ray hit nothing): n groups per light
+        // the shadow queue is compact (one group per ray that hit something, in ray order; its count is on the device): the launches
+        // get the grid of all n rays of the step and blocks past the count leave at once
         if (opt->shadow_samples > 0) {
             for (size_t li = 0; li < s->lights.size(); ++li) {
                 uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194

@@ -2251,8 +2251,8 @@ DEV float grp_max(float v) {
 // MULTI = false: the 16 lanes of a group are feelers of ONE hit point (tries a multiple of 16).
 // MULTI = true:  tries is 4 or 8 and a group holds the feelers of 16 / tries neighbouring hit points.  Such a
 //                group is walked only if its hit points lie close together (RTX_COOP_WIDE); the others (a ground
-//                plane seen near the horizon, a silhouette) are left in the queue for the per-lane kernel that
-//                runs next, and every queue entry this kernel has finished is marked empty.
+//                plane seen near the horizon, a silhouette) go on a list (DShadowQ.wide) for the per-lane kernel that
+//                runs next; every queue entry this kernel has finished is also marked empty.
 #ifndef RTX_COOP_WIDE
 #define RTX_COOP_WIDE 0.02f   // largest spread of a group's hit points, as a fraction of the scene's radius
 #endif

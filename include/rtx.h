@@ -269,15 +269,17 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_camera *camera, const r
                              void *rgba_out_dev, void *primary_prim_id_out_dev, void *stream,
                              rtx_stats *stats);
 
-/* NO COUNTERPART IN THE REFERENCE.  rtx_render_device for callers that cannot allocate: code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  Same arguments, same frame (to the order of the f64 atomic adds), but the call
+/* NO COUNTERPART IN THE REFERENCE.  rtx_render_device for callers that cannot allocate: tight serving loops, harnesses that
+ * forbid hipMalloc, code that must not touch the allocator between two of its own captures.  (NOT capturable itself: the call
+ * synchronises `stream` once per wavefront step, because the host sizes each launch from the step's counters.)  Same arguments, same frame (to the order of the f64 atomic adds), but the call
  * allocates nothing: no hipMalloc / hipFree / hipHostMalloc, no stream or event creation, no host heap.  Its workspace (ray pool,
  * shadow queue, hit records, counters, sample accumulators) is carved out of a static 32 MiB device array that every GPU the
  * library runs on holds until the process ends; the batch shrinks until the call fits, and a call that cannot fit (the
  * accumulators alone take 24 bytes per primary sample: about 1.3 M samples at most; reflect_depth + refract_depth above 62) fails
  * with RTX_ERR_LIMIT.  Larger frames go through in pieces with shard_index / shard_count (8-row blocks).  Every launch runs on
- * `stream` (as with RTX_FLAG_SERIAL), the call returns when the frame is complete, rtx_options.pool_rays is ignored, and the
- * timing fields of `stats` stay 0.  All calls on one GPU share that GPU's array: calls that overlap on one GPU race (one call at
+ * `stream` (as with RTX_FLAG_SERIAL), the call returns when the frame is complete (it synchronises `stream` after the resolve, so
+ * the next call's clearing of the shared array cannot overtake it), rtx_options.pool_rays is ignored, and the timing fields of
+ * `stats` (ms_*) stay 0.  All calls on one GPU share that GPU's array: calls that overlap on one GPU race (one call at
  * a time per GPU, whatever the scene handle); the array keeps the last call's contents and each call clears what it needs. */
 rtx_status rtx_render_device_noalloc(rtx_scene *scene, const rtx_camera *camera, const rtx_options *options,
                                      void *rgba_out_dev, void *primary_prim_id_out_dev, void *stream, rtx_stats *stats);

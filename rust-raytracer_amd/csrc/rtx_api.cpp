@@ -978,7 +978,12 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                     if (sq_free[i][a]) HIPCHECK(hipStreamWaitEvent(stream, sq_free[i][a], 0));
         rtxk_resolve(stream, fr, v.acc, d_rgba);
         HIPCHECK(hipGetLastError());
-        if (!stats && !uses_retry) return RTX_OK;   // nothing to read back: the call returns with the frame enqueued
+        if (!stats && !uses_retry) {
+            // nothing to read back: rtx_render_device returns with the frame enqueued; the allocation-free variant returns when the
+            // frame is complete (rtx.h: the next call on this GPU clears the shared static array, whatever stream it runs on)
+            if (noalloc) HIPCHECK(hipStreamSynchronize(stream));
+            return RTX_OK;
+        }
 
         unsigned long long slots_stack[RTX_RAY_SLOTS][RTX_RAY_SLOT_WORDS];   // 64 KB
         unsigned long long (*h_slots)[RTX_RAY_SLOT_WORDS] = noalloc ? slots_stack : w.h_ray_slots;
@@ -1019,7 +1024,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         stats->launches_closest = launches_closest;
         stats->launches_shadow = launches_shadow;
         stats->peak_pool_rays = peak_pool;
-        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        if (!noalloc) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         return RTX_OK;
     };
     if ((st = finish())) return bail(st);

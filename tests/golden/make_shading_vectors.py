@@ -55,9 +55,14 @@ def inputs():
         o = rng.uniform(-3, 3, size=3)
         d = unit(rng.normal(size=3))
         if k % 3 == 0:                                               # axis-parallel: zero components, inf inverse
-            d = np.eye(3)[k % 3 - 0] * (1.0 if k % 2 else -1.0)
+            ax = (k // 3) % 3
+            d = np.eye(3)[ax] * (1.0 if k % 2 else -1.0)                # all three axes, both signs
+            if (k // 6) % 2:                                            # half of them aimed at the box's cross-section: hits as well as misses
+                for b in range(3):
+                    if b != ax:
+                        o[b] = lo[b] + (hi[b] - lo[b]) * (0.25 + 0.5 * ((k // 12 + b) % 2))
         if k % 7 == 0:
-            o[k % 3] = lo[k % 3]                                     # origin on a face plane (0 * inf = NaN with a zero component)
+            o[(k // 7) % 3] = lo[(k // 7) % 3]                       # origin on a face plane (0 * inf = NaN with a zero component), any axis
         rows.append([*lo, *hi, *o, *d])
     g["bbox"] = ("BBOX", "kitchen", rows)
     # kitchen sink: textures 0 image, 1 uv, 2 checker; materials 0..5 (CT+image, Phong+uv, Phong+checker, Flat, CT mirror, CT glass)

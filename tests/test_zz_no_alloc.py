@@ -51,6 +51,35 @@ def test_noalloc_entry_point_matches_render_device(rtx):
     sc2.close()
 
 
+def test_noalloc_entry_point_allocates_nothing(rtx):
+    """What the entry point exists for: on a FRESH scene handle (no workspace, no aux streams, no events yet: rtx_render_device has
+    never run on it) a call must leave the device's free memory exactly as it found it.  A regression that routes the call
+    through ensure_work() (ray pool, shadow queues: tens of MB) or creates streams / events would move it."""
+    import torch
+    flat, cam_fn = scenes.mesh_scene(rtx, n_u=32, n_v=24)
+    cam = cam_fn(128, 80)
+    rgba = torch.zeros((80, 128, 4), dtype=torch.uint8, device="cuda")
+    ids = torch.zeros((80, 128), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    sc = rtx.Scene(flat)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for opt in (rtx.options(reflect_depth=3, refract_depth=3, shadow_samples=16, pixel_samples=2, rng_mode=1, seed=1),
+                rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=4, pixel_samples=1, rng_mode=1, seed=2),
+                rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=1, pixel_samples=1, rng_mode=1, seed=3)):
+        st = sc.render_device_noalloc(cam, opt, rgba.data_ptr(), ids.data_ptr(), stream)
+        assert st.rays_primary > 0
+        assert st.ms_total == 0.0 and st.ms_device == 0.0      # rtx.h: the timing fields stay 0
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, (free0, free1)
+    # the same handle's first rtx_render_device DOES allocate its workspace: the probe sees allocations of this size
+    sc.render_device(cam, rtx.options(reflect_depth=2, refract_depth=2, shadow_samples=1, pixel_samples=1, rng_mode=1, seed=3), rgba.data_ptr(), ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free2 < free0
+    sc.close()
+
+
 def test_noalloc_entry_point_rejects_what_does_not_fit(rtx):
     import torch
     flat, cam_fn = scenes.sphere_scene(rtx)

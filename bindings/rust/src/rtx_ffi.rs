@@ -183,6 +183,8 @@ pub struct RtxSceneInfo {
     pub root_max: [f64; 3],
     pub wide_nodes: i32,
     pub wide_depth: i32,
+    pub bvh4_nodes: i32,
+    pub hierarchy_on_device: i32,
 }
 
 /// Opaque handle (`typedef struct rtx_scene rtx_scene`).
@@ -212,6 +214,7 @@ extern "C" {
     pub fn rtx_shade_probe(scene: *mut RtxScene, which: i32, n: i64, input: *const f64, out: *mut f64) -> RtxStatus;
     pub fn rtx_octree_dump(desc: *const RtxSceneDesc, depth: *mut i32, n_nodes: *mut i64, n_entries: *mut i64,
                            bbox_out: *mut f64, shape_out: *mut i32, entries_out: *mut i32) -> RtxStatus;
+    pub fn rtx_hierarchy_dump(scene: *mut RtxScene, which: i32, out: *mut c_void, cap_bytes: i64, n_bytes: *mut i64) -> RtxStatus;
     pub fn rtx_strerror(status: RtxStatus) -> *const c_char;
     pub fn rtx_last_error() -> *const c_char;
     pub fn rtx_version() -> *const c_char;

@@ -233,6 +233,8 @@ typedef struct rtx_scene_info {
     double root_min[3], root_max[3];
     int32_t wide_nodes;       /* 16-wide box lists of the cooperative shadow traversal (0: not used) */
     int32_t wide_depth;
+    int32_t bvh4_nodes;       /* 4-wide nodes of the per-lane walks (0: not used) */
+    int32_t hierarchy_on_device;   /* 1: both cuts of the SAH tree were built by the device-side builder, 0: by the host's */
 } rtx_scene_info;
 
 typedef struct rtx_scene rtx_scene;
@@ -332,6 +334,14 @@ rtx_status rtx_shade_probe(rtx_scene *scene, int32_t which, int64_t n, const dou
  * empty scene).  Pass NULL for the three arrays to query the sizes only. */
 rtx_status rtx_octree_dump(const rtx_scene_desc *desc, int32_t *depth, int64_t *n_nodes, int64_t *n_entries,
                            double *bbox_out, int32_t *shape_out, int32_t *entries_out);
+
+/* Diagnostic: the SAH hierarchy rtx_scene_create built for the scene, copied back from the device as it lies there.  No
+ * counterpart in the reference (octree.rs:15-43 builds the octree; this is the structure the walks use beside it).
+ * which = 0: the 16-wide box lists (32-byte children: float lo[3], hi[3], uint32 ref, uint32 first_node; 16 per node),
+ * which = 1: the 4-wide nodes (112 bytes: float lo[3][4], hi[3][4], uint32 ref[4]).  *n_bytes receives the array's size; the copy is
+ * made when out != NULL and cap_bytes >= that size.  tests/test_gpu_build.py compares the device-side builder's arrays with the
+ * host builder's (RTX_BUILD_HIERARCHY=host|device). */
+rtx_status rtx_hierarchy_dump(rtx_scene *scene, int32_t which, void *out, int64_t cap_bytes, int64_t *n_bytes);
 
 const char *rtx_strerror(rtx_status status);
 /* Last error text recorded by this thread (HIP error strings, limit details). Never NULL. */

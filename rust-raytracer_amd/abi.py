@@ -118,13 +118,14 @@ class SceneInfo(C.Structure):
         ("max_leaf_entries", C.c_int32), ("all_opaque", C.c_int32), ("device_bytes", C.c_int64),
         ("root_min", C.c_double * 3), ("root_max", C.c_double * 3),
         ("wide_nodes", C.c_int32), ("wide_depth", C.c_int32),
+        ("bvh4_nodes", C.c_int32), ("hierarchy_on_device", C.c_int32),
     ]
 
 
 # every symbol include/rtx.h declares
 EXPORTS = (
     "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_get_info", "rtx_render",
-    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_shade_probe", "rtx_octree_dump", "rtx_strerror",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_shade_probe", "rtx_octree_dump", "rtx_hierarchy_dump", "rtx_strerror",
     "rtx_last_error", "rtx_version",
 )
 
@@ -170,6 +171,8 @@ def load():
     lib.rtx_octree_dump.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), vp, vp, vp]
     lib.rtx_octree_dump.restype = C.c_int32
+    lib.rtx_hierarchy_dump.argtypes = [vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
+    lib.rtx_hierarchy_dump.restype = C.c_int32
     lib.rtx_strerror.argtypes = [C.c_int32]
     lib.rtx_strerror.restype = C.c_char_p
     lib.rtx_last_error.argtypes = []

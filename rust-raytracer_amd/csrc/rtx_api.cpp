@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "rtx_bvh.h"
+#include "rtx_build.h"
 #include "rtx_device.h"
 
 namespace {
@@ -424,6 +425,9 @@ struct rtx_scene {
     std::vector<rtx_light> lights;
     bool any_reflective = false, any_refractive = false, any_glossy = false;
     int n_materials = 0, n_textures = 0;
+    int64_t n_wide_nodes = 0, n_bvh4_nodes = 0;   // sizes of d.wide / d.bvh4 as built (rtx_hierarchy_dump)
+    const DWideChild *wide_built = nullptr;       // (d.wide / d.bvh4 are cleared when a walk cannot use them; the dump shows what was built)
+    const DNode4 *bvh4_built = nullptr;
     Work w;
 };
 
@@ -1082,6 +1086,46 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     lap("validate + device");
     const unsigned n_threads_env = build_threads();
     RtxPool pool(std::max(1u, n_threads_env));
+    // The SAH hierarchy (16-wide box lists + 4-wide nodes) is built ON THE DEVICE (rtx_build.hip), on a thread of its own beside the
+    // host's octree build: it needs the finite prims' boxes and the root centre only.  RTX_BUILD_HIERARCHY=host keeps the host
+    // builder (rtx_bvh.cpp: the same tree, the A/B and the cross-check of tests/test_gpu_build.py); scenes below
+    // RTX_DEVICE_BUILD_MIN prims take it too unless RTX_BUILD_HIERARCHY=device (a device build is ~60 launches whatever the size).
+    const int n_fin0 = (int)fl.fin_kind.size();
+    std::vector<RtxPrimBox> pboxes((size_t)n_fin0);
+    pool.run(((size_t)n_fin0 + 16383) / 16384, [&](size_t chunk) {
+        for (int i = (int)(chunk * 16384); i < std::min(n_fin0, (int)((chunk + 1) * 16384)); ++i) {
+            const HBox &pb = fl.oct.prim_box[(size_t)i];
+            for (int a = 0; a < 3; ++a) { pboxes[(size_t)i].mn[a] = pb.mn[a]; pboxes[(size_t)i].mx[a] = pb.mx[a]; }
+            const uint32_t idx = (uint32_t)fl.fin_index[(size_t)i];
+            pboxes[(size_t)i].ref = fl.fin_kind[(size_t)i] == RTX_PRIM_TRIANGLE ? (RTX_WREF_TRI | idx) : (RTX_WREF_SPHERE | idx);
+        }
+    });
+    const HBox root_box = fl.oct.root_bounds();   // = the octree root's box (octree.rs:24-25)
+    double centre[3], radius = 0.0;
+    for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (root_box.mn[a] + root_box.mx[a]);
+    for (int a = 0; a < 3; ++a)
+        radius = std::max(radius, std::max(std::fabs(root_box.mn[a] - centre[a]), std::fabs(root_box.mx[a] - centre[a])));
+    radius *= 1.0 + 1.0e-12;
+    const char *hb_env = std::getenv("RTX_BUILD_HIERARCHY");
+    const bool device_build = n_fin0 >= 2 && d->n_triangles < (1 << 30) && d->n_spheres < (1 << 30) &&
+                              (hb_env ? std::strcmp(hb_env, "device") == 0 : n_fin0 >= RTX_DEVICE_BUILD_MIN);
+    if (hb_env && std::strcmp(hb_env, "device") != 0 && std::strcmp(hb_env, "host") != 0)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "RTX_BUILD_HIERARCHY must be `host` or `device`");
+    RtxDeviceHierarchy dh;
+    int dh_rc = 0;
+    std::string dh_err;
+    std::thread dh_thread;
+    if (device_build)
+        dh_thread = std::thread([&]() {
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) { dh_rc = (int)e; dh_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return; }
+            dh_rc = rtxk_build_hierarchies_device(pboxes.data(), (int64_t)n_fin0, centre, &dh, timing, &dh_err);
+        });
+    struct Joiner {   // no path out of this function leaves the thread running (it reads pboxes / centre)
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } dh_joiner{dh_thread};
+    lap("prim boxes, device build started");
     build_octree(fl, n_threads_env ? &pool : nullptr);
     lap("octree");
     const HostOctree &oct = fl.oct;
@@ -1216,23 +1260,22 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     // The conservative f32 twins (DNode32 / DEntry32: boxes relative to the root centre, rounded outward) are derived ON THE DEVICE
     // from the uploaded f64 records (rtxk_build_twins below): nothing of them is built or copied by the host.
     // Every box lies inside the root's (the union of the prim boxes; child boxes can leave it by an ulp of rounding).
-    double centre[3], radius = 0.0;
-    for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (oct.nodes[0].bbox.mn[a] + oct.nodes[0].bbox.mx[a]);
-    for (int a = 0; a < 3; ++a)
-        radius = std::max(radius, std::max(std::fabs(oct.nodes[0].bbox.mn[a] - centre[a]), std::fabs(oct.nodes[0].bbox.mx[a] - centre[a])));
-    radius *= 1.0 + 1.0e-12;
-    // 16-wide box lists for the cooperative any-hit traversal
-    std::vector<RtxPrimBox> pboxes((size_t)n_fin);
-    for (int i = 0; i < n_fin; ++i) {
-        const HBox &pb = oct.prim_box[(size_t)i];
-        for (int a = 0; a < 3; ++a) { pboxes[(size_t)i].mn[a] = pb.mn[a]; pboxes[(size_t)i].mx[a] = pb.mx[a]; }
-        int32_t r = ref_of_prim[(size_t)i];
-        pboxes[(size_t)i].ref = r >= 0 ? (RTX_WREF_TRI | (uint32_t)r) : (RTX_WREF_SPHERE | (uint32_t)(~r));
-    }
+    // 16-wide box lists for the cooperative any-hit traversal, 4-wide nodes for the per-lane walks
     std::vector<DWideChild> wide;
     std::vector<DNode4> bvh4;
     RtxWideStats wstats;
-    rtx_build_hierarchies(pboxes, centre, wide, bvh4, &wstats, pool);
+    if (device_build) {
+        dh_thread.join();
+        if (dh_rc != 0) return cleanup(fail(dh_rc == (int)hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP, dh_err));
+        s->allocs.push_back(dh.wide);
+        s->allocs.push_back(dh.bvh4);
+        wstats = dh.stats;
+        if (timing)
+            std::fprintf(stderr, "    device build: upload %.2f, %d binned levels %.2f, small subtrees %.2f, collapse DP %.2f, emission %.2f ms\n",
+                         dh.ms_upload, dh.levels, dh.ms_tree, dh.ms_small, dh.ms_dp, dh.ms_emit);
+    } else {
+        rtx_build_hierarchies(pboxes, centre, wide, bvh4, &wstats, pool);
+    }
     // k_shadow_coop's level stack (24 levels), queue entry bits, 23-bit prim index of a waiting pair
     const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 26) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
     // traverse_bvh's stack entries: node index | quantised entry distance (at least 6 bits of it)
@@ -1240,9 +1283,15 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     while ((1ll << bvh4_bits) < wstats.nodes4) ++bvh4_bits;
     // (traverse_bvh packs a primitive's index into 24 bits of a pair word)
     const bool bvh4_ok = bvh4_bits <= 26 && d->n_triangles < (1 << 24) && d->n_spheres < (1 << 24) && std::getenv("RTX_NO_BVH4") == nullptr;
-    lap("hierarchies (SAH)");
-    up.submit(wide, &ds.wide);
-    up.submit(bvh4, &ds.bvh4);
+    lap(device_build ? "hierarchies (joined device build)" : "hierarchies (SAH, host)");
+    if (device_build) {
+        ds.wide = dh.wide;
+        ds.bvh4 = dh.bvh4;
+        s->info.device_bytes += (int64_t)(wstats.nodes * RTX_WIDE * (int64_t)sizeof(DWideChild) + wstats.nodes4 * (int64_t)sizeof(DNode4));
+    } else {
+        up.submit(wide, &ds.wide);
+        up.submit(bvh4, &ds.bvh4);
+    }
     // the inverse of the leaf lists (which leaves list a prim), for the two-phase shadow product of scenes with transmissive materials
     std::vector<int32_t> prim_leaf_begin, prim_leaves;
     if (!all_opaque && bvh4_ok) {
@@ -1275,6 +1324,10 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipGetLastError());
     lap("f32 twins (device)");
+    s->wide_built = ds.wide;
+    s->bvh4_built = ds.bvh4;
+    s->n_wide_nodes = wstats.nodes;
+    s->n_bvh4_nodes = wstats.nodes4;
     if (!wide_ok) ds.wide = nullptr;   // too deep for the LDS stack: shadows fall back to the per-lane walk
     if (!bvh4_ok) ds.bvh4 = nullptr;   // the per-lane walks fall back to the octree
     ds.bvh4_node_bits = bvh4_bits;
@@ -1303,6 +1356,8 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     info.all_opaque = ds.all_opaque;
     info.wide_nodes = ds.wide ? (int32_t)wstats.nodes : 0;
     info.wide_depth = wstats.depth;
+    info.bvh4_nodes = ds.bvh4 ? (int32_t)wstats.nodes4 : 0;
+    info.hierarchy_on_device = device_build ? 1 : 0;
     for (int a = 0; a < 3; ++a) { info.root_min[a] = nodes[0].bmin[a]; info.root_max[a] = nodes[0].bmax[a]; }
     *out = s.release();
     return RTX_OK;
@@ -1320,6 +1375,18 @@ rtx_status rtx_scene_destroy(rtx_scene *s) {
 rtx_status rtx_scene_get_info(const rtx_scene *s, rtx_scene_info *info) {
     if (!s || !info) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
     *info = s->info;
+    return RTX_OK;
+}
+
+rtx_status rtx_hierarchy_dump(rtx_scene *s, int32_t which, void *out, int64_t cap_bytes, int64_t *n_bytes) {
+    if (!s || !n_bytes || which < 0 || which > 1) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_hierarchy_dump: bad argument");
+    const void *src = which == 0 ? (const void *)s->wide_built : (const void *)s->bvh4_built;
+    const int64_t bytes = which == 0 ? s->n_wide_nodes * RTX_WIDE * (int64_t)sizeof(DWideChild) : s->n_bvh4_nodes * (int64_t)sizeof(DNode4);
+    *n_bytes = src ? bytes : 0;
+    if (!out || !src) return RTX_OK;
+    if (cap_bytes < bytes) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_hierarchy_dump: buffer too small");
+    HIPCHECK(hipSetDevice(s->device));
+    HIPCHECK(hipMemcpy(out, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 

@@ -38,6 +38,21 @@ class Scene:
         abi.check(self._lib.rtx_scene_get_info(self.h, C.byref(inf)), "rtx_scene_get_info")
         return inf
 
+    def hierarchy_dump(self):
+        """rtx_hierarchy_dump: the SAH hierarchy as it lies on the device: (wide, bvh4) structured numpy arrays
+        (wide[n, 16] of DWideChild, bvh4[n] of DNode4; empty arrays where a cut was not built)."""
+        wide_t = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("ref", "<u4"), ("first_node", "<u4")])
+        bvh4_t = np.dtype([("lo", "<f4", (3, 4)), ("hi", "<f4", (3, 4)), ("ref", "<u4", 4)])
+        out = []
+        for which, dt in ((0, wide_t), (1, bvh4_t)):
+            nb = C.c_int64()
+            abi.check(self._lib.rtx_hierarchy_dump(self.h, which, None, 0, C.byref(nb)), "rtx_hierarchy_dump")
+            arr = np.zeros(nb.value // dt.itemsize, dtype=dt)
+            if nb.value:
+                abi.check(self._lib.rtx_hierarchy_dump(self.h, which, arr.ctypes.data_as(C.c_void_p), nb.value, C.byref(nb)), "rtx_hierarchy_dump")
+            out.append(arr)
+        return out[0].reshape(-1, 16), out[1]
+
     def render(self, cam, opt, want_ids=True, out=None):
         """rtx_render into host arrays: returns (rgba[H,W,4] u8, prim_id[H,W] i32 or None, Stats)."""
         H, W = cam.image_height, cam.image_width

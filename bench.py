@@ -74,6 +74,12 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="--animate: render only the first K frames of the animation")
     ap.add_argument("--fps", type=float, default=25.0)
     ap.add_argument("--time-slice", type=float, nargs=2, default=(0.0, 7.0))
+    ap.add_argument("--pmc", default="auto", choices=("auto", "profile", "off"),
+                    help="roofline counters: auto = collect them now (rocprofv3 --pmc passes on child runs of this workload; falls back to the "
+                         "committed profile), profile = profiles/pmc_traffic.json only, off = no counters")
+    ap.add_argument("--save-profile", default="", help="TAG: keep the counter passes of this run as <profile-dir>/TAG_pmc_<workload>.json and in <profile-dir>/pmc_traffic.json")
+    ap.add_argument("--profile-dir", default=os.path.join(ROOT, "profiles"))
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # a child run under the profiler / the counting library: no extras
     ap.add_argument("--force", action="store_true", help="run a heptoroid configuration whose estimated ray count is above 1e11")
     args = ap.parse_args()
 
@@ -176,11 +182,21 @@ def main():
         dist.all_reduce(agg[:5], op=dist.ReduceOp.SUM)
         agg[5] = tmax[0]
     agg = agg.cpu().numpy()
+    # each rank's own frame time (render + its share of the gather): load balance of the interleaved blocks
+    mine_ms = torch.tensor([elapsed / max(1, args.steps) * 1e3], dtype=torch.float64, device=comm_dev)
+    if world > 1:
+        all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
+        per_rank = [float(t.item()) for t in all_ms]
+    else:
+        per_rank = [float(mine_ms.item())]
+    per_rank_ms = {"min": min(per_rank), "max": max(per_rank), "by_rank": [round(x, 3) for x in per_rank]}
     total_rays, elapsed = float(agg[:5].sum()), float(agg[5])
 
     if rank == 0:
         steps = max(1, args.steps)
         ms_closest = sum(s.ms_closest for s in stats) / steps
+        ms_shade = sum(s.ms_shade for s in stats) / steps
         ms_shadow = sum(s.ms_shadow for s in stats) / steps
         l_closest = sum(s.launches_closest for s in stats) / steps
         l_shadow = sum(s.launches_shadow for s in stats) / steps
@@ -197,14 +213,16 @@ def main():
                        "triangles": int(named.n_triangles), "octree_depth": int(info.octree_depth),
                        "octree_nodes": int(info.n_nodes), "leaf_entries": int(info.n_leaf_entries),
                        "sharding": "8-row tile blocks interleaved over ranks + RCCL gather to rank 0",
+                       "hierarchy_built_on_device": bool(info.hierarchy_on_device),
                        "scene_generate_s": round(generate_s, 3), "scene_build_upload_s": round(build_s, 3),
                        "scene_build_upload_warm_s": round(build_warm_s, 3)},
             "frame_ms": elapsed / steps * 1e3,
             "rays_per_frame": {"primary": float(agg[0]) / steps, "reflect": float(agg[1]) / steps,
                                "gloss": float(agg[2]) / steps, "refract": float(agg[3]) / steps,
                                "shadow": float(agg[4]) / steps},
-            "device_ms_rank0": {"frame": sum(s.ms_device for s in stats) / steps, "closest_shade": ms_closest,
+            "device_ms_rank0": {"frame": sum(s.ms_device for s in stats) / steps, "closest_shade": ms_closest, "shade": ms_shade,
                                 "shadow": ms_shadow, "launches_closest": l_closest, "launches_shadow": l_shadow},
+            "per_rank_frame_ms": per_rank_ms,
         }
 
         wk = [[int(r0.work[c][k]) for k in range(3)] for c in range(2)]
@@ -213,85 +231,319 @@ def main():
                 "closest": dict(zip(("nodes", "leaf_entries", "prim_tests"), [w / max(1, closest_rays) for w in wk[0]])),
                 "shadow": dict(zip(("nodes", "leaf_entries", "prim_tests"), [w / max(1, r0.rays_shadow) for w in wk[1]]))}
 
-        cpu = None
-        if args.cpu_blocks > 0 and world == 1:   # the CPU baseline (and the roofline built on its counters) is an N=1 figure
-            orc = importlib.import_module("oracle.oracle")   # the checker + CPU baseline, never the product
-            threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-            oscene = orc.Scene(named)
-            ocn = orc.Counters()
-            opt_cpu = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
-                                  pixel_samples=ps, rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0)
-            picks = sorted({int((k + 0.5) * n_blocks / args.cpu_blocks) for k in range(args.cpu_blocks)})
-            gpu_img = final.cpu().numpy()
-            ok = tot = 0
-            for b in picks:
-                o_rgba, _, cn = oscene.render(cam, opt_cpu, threads=threads, rows=(b * 8, b * 8 + 8), cols=(0, W), want_ids=False)
-                ocn.add(cn)
-                d = np.abs(o_rgba[b * 8:b * 8 + 8, :, :3].astype(np.int32) - gpu_img[b * 8:b * 8 + 8, :, :3].astype(np.int32)).max(axis=-1)
-                ok += int((d <= 1).sum())
-                tot += d.size
-            cpu = {"value": ocn.rays_total / ocn.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",   # a SAMPLE of the frame:
-                   "sample": "tile-block rows %s (8 rows x %d px each) of the same %dx%d frame, same options; %d rays in %.1f s"
-                             % (picks, W, W, H, ocn.rays_total, ocn.seconds)}
-            out["cpu_baseline"] = cpu
-            out["gpu_over_cpu"] = out["value"] / cpu["value"]
-            out["parity_sample"] = {"rgb_within_1": ok / max(1, tot), "pixels": tot}
-            # reference-order algorithmic bytes per ray of each class
-            b_closest = ocn.algorithmic_bytes(0) / max(1, ocn.rays_closest)
-            b_shadow = ocn.algorithmic_bytes(1) / max(1, ocn.rays[4])
-            if ms_shadow >= ms_closest and l_shadow > 0:
-                kname, ms, launches, nrays, bpr = "k_shadow", ms_shadow, l_shadow, float(r0.rays_shadow), b_shadow
-            else:
-                kname, ms, launches, nrays, bpr = "k_trace", ms_closest, l_closest, float(closest_rays), b_closest
-            avg_ms = ms / max(1.0, launches)
-            # what the byte model of SURVEY.md 8d gives: reference-order algorithmic bytes (oracle traversal counters: every pierced
-            # leaf, no early-out) x rays / launch time / HBM peak.  The kernels never move those bytes: a work-avoidance figure.
-            ref_order_gbs = bpr * (nrays / max(1.0, launches)) / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = {}
-            try:   # HBM bytes per launch of that kernel + SQ counters from separate rocprofv3 --pmc passes (profiles/)
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                    allpmc = json.load(fh)
-                    pmc = allpmc.get(args.workload, {})
-                    traffic = pmc.get(kname)
-                    pmc_source = allpmc.get("_source")
-            except (OSError, ValueError):
-                pmc_source = None
-            v = pmc.get(kname + "_valu") or {}
-            frac = (v.get("busy") * v.get("lane_utilisation")) if v else None
-            out["roofline"] = {
-                "bound": "valu", "kernel": {"k_shadow": "k_shadow_coop<false>", "k_trace": "k_closest<5> (+ k_shade)"}[kname],
-                "achieved": frac * VALU_LANE_SLOTS if frac is not None else None, "peak": VALU_LANE_SLOTS,
-                "unit": "VALU lane-slots per cycle doing a lane's work (256 CUs x 4 SIMDs x 16 lanes)",
-                "frac": frac,
-                "valu_busy": v.get("busy"), "lane_utilisation": v.get("lane_utilisation"),
-                "valu_insts_per_wave": v.get("valu_insts_per_wave"),
-                "hbm_frac": (v.get("hbm_gbs_alone") / HBM_PEAK_GBS) if v else None,
-                "l2_frac": (v.get("l2_request_gbs") / L2_PEAK_GBS) if v else None,
-                "hbm_gbs_alone": v.get("hbm_gbs_alone"), "l2_request_gbs": v.get("l2_request_gbs"), "l2_hit_rate": v.get("l2_hit_rate"),
-                "traffic": traffic,   # measured HBM bytes per launch: (FETCH_SIZE x2 + WRITE_SIZE) x 1024 / launches
-                "avg_launch_ms": avg_ms,   # live, HIP events on the launch's own stream
-                "avg_launch_ms_alone_profiled": v.get("alone_ms_per_launch"),
-                "launches_per_frame": launches, "rays_per_launch": nrays / max(1.0, launches),
-                # > 1: launches run concurrently (the shadow launches of the two lights on the library's two
-                # streams, next to the following step's closest-hit launch), so avg_launch_ms is a duration
-                # under sharing; `bench.py --serial` times every kernel alone (profiles/*_serial*)
-                "launch_concurrency": (ms_shadow + ms_closest) / max(1e-9, out["device_ms_rank0"]["frame"]),
-                "overlap": not args.serial,
-                "algorithmic_bytes_per_ray_reference_order": bpr,
-                "work_avoidance_vs_reference_order": ref_order_gbs / HBM_PEAK_GBS,
-                "source": pmc_source,
-                "note": "the dominant kernel is VALU-issue bound on cache-resident data: frac = valu_busy x lane_utilisation from the "
-                        "rocprofv3 SQ pass of the kernel alone (committed under profiles/, not collected in this run); hbm_frac and "
-                        "l2_frac say how far it is from the memory bounds; work_avoidance_vs_reference_order is the SURVEY.md 8d byte "
-                        "model (bytes the reference's unordered walk would move per ray x rays / launch time / 8 TB/s), > 1 because the "
-                        "ordered, culled, cooperative traversal does not move them: not a roofline fraction"}
+        if world == 1 and not args.child:
+            measure(args, pkg, np, torch, out, scene, named, cam, opt, rgba, final, stream, W, H, n_blocks,
+                    refl, refr, shadow, gloss, ps, stats, closest_rays)
         print(json.dumps(out), flush=True)
 
     scene.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_PASSES = (   # separate rocprofv3 --pmc runs, each within one pass's counter limits (8 SQ, 4 TCC, 2 GRBM)
+    ("f", ["FETCH_SIZE", "TCC_HIT_sum"]),
+    ("w", ["WRITE_SIZE", "TCC_MISS_sum", "TCC_REQ_sum"]),
+    ("s", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_WAIT_ANY",
+           "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"]),
+)
+
+
+def reference_num_cpus():
+    """What num_cpus::get() gives the reference (main.rs:138 sizes its thread pool with it): the logical CPUs this process may use =
+    min(scheduler affinity, cgroup CPU quota)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / pr)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def short_kernel_name(name):
+    """'void k_shadow_coop<false>(DScene, ...)' -> 'k_shadow_coop<false>' (the names rtx_last_kernel_names reports)."""
+    import re
+    nm = name.replace("(anonymous namespace)::", "")
+    m = re.match(r"(?:void\s+)?([\w:]+(?:<[^()]*?>)?)\s*\(", nm)
+    return m.group(1) if m else nm.split("(")[0].strip()
+
+
+def child_cmd(args, extra):
+    cmd = ["python3", os.path.join(ROOT, "bench.py"), "--child", "--pmc", "off", "--cpu-blocks", "0", "--workload", args.workload,
+           "--detail", str(args.detail), "--batch-rays", str(args.batch_rays), "--reflect", str(args.reflect), "--refract", str(args.refract)]
+    if args.width:
+        cmd += ["--width", str(args.width)]
+    if args.height:
+        cmd += ["--height", str(args.height)]
+    if args.no_coop:
+        cmd.append("--no-coop")
+    if args.force:
+        cmd.append("--force")
+    return cmd + extra
+
+
+def collect_pmc(args):
+    """Three rocprofv3 --pmc passes over `bench.py --serial --steps 1 --warmup 0` of this workload (child processes; the profiler
+    serialises dispatches, so every figure is the kernel running alone).  Returns {kernel: {counter: sum, '_seconds', '_dispatches'}}
+    per pass, or raises."""
+    import collections
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="rtx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RTX_LIB", None)
+    res = {}
+    for tag, counters in PMC_PASSES:
+        cmd = ["timeout", "-s", "KILL", "150", rocprof, "--pmc"] + counters + ["-d", os.path.join(tmp, tag), "-o", tag, "--"] + \
+              child_cmd(args, ["--steps", "1", "--warmup", "0", "--serial"])   # (the kernels of the frame that is timed alone)
+        pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if pr.returncode != 0:
+            raise RuntimeError("rocprofv3 pass %s failed (%d): %s" % (tag, pr.returncode, pr.stdout[-400:]))
+        dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(tmp, tag)) for f in fs if f.endswith(".db")]
+        if not dbs:
+            raise RuntimeError("rocprofv3 pass %s left no database" % tag)
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        con = sqlite3.connect(dbs[0])
+        seen = set()
+        for name, did, cname, val, start, end in con.execute(
+                "select kernel_name, dispatch_id, counter_name, value, start, end from counters_collection"):
+            k = short_kernel_name(name)
+            agg[k][cname] += float(val)
+            if did not in seen:
+                seen.add(did)
+                agg[k]["_seconds"] += (int(end) - int(start)) * 1e-9
+                agg[k]["_dispatches"] += 1
+        con.close()
+        res[tag] = {k: dict(v) for k, v in agg.items()}
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def derive_pmc(res):
+    """Per kernel, from the three passes (units and the gfx950 corrections as the micro-architecture guide prescribes: FETCH_SIZE /
+    WRITE_SIZE in KB, FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2; SQ_ACTIVE_INST_* in quad-cycles; GRBM_GUI_ACTIVE summed
+    over the 8 XCDs)."""
+    out = {}
+    f, w, s = res["f"], res["w"], res["s"]
+    total_s = sum(c.get("_seconds", 0.0) for c in s.values()) or 1.0
+    for k, c in s.items():
+        if k not in f or k not in w or not c.get("SQ_WAVES"):
+            continue
+        simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * 1024
+        launches = max(1.0, c["_dispatches"])
+        hbm_bytes = (f[k].get("FETCH_SIZE", 0.0) * 2 + w[k].get("WRITE_SIZE", 0.0)) * 1024
+        busy = c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles if simd_cycles else 0.0
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) if c.get("SQ_ACTIVE_INST_VALU") else 0.0
+        out[k] = {"busy": busy, "lane_utilisation": lanes,
+                  "valu_insts_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
+                  "waves_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                  "l2_hit_rate": 1.0 - w[k]["TCC_MISS_sum"] / w[k]["TCC_REQ_sum"] if w[k].get("TCC_REQ_sum") else None,
+                  "l2_request_gbs": w[k].get("TCC_REQ_sum", 0.0) * 128 / w[k]["_seconds"] / 1e9,
+                  "hbm_gbs_alone": hbm_bytes / w[k]["_seconds"] / 1e9,
+                  "hbm_bytes_per_launch": hbm_bytes / launches,
+                  "hbm_write_bytes_per_launch": w[k].get("WRITE_SIZE", 0.0) * 1024 / launches,
+                  "alone_ms_per_launch": c["_seconds"] * 1e3 / launches, "launches": launches,
+                  "share_of_kernel_time": c["_seconds"] / total_s}
+    return out
+
+
+def count_work(args):
+    """What the kernels themselves walked: one frame through librtx_count.so (the profiling twin, -DRTX_COUNT_WORK) in a child
+    process; returns its gpu_work_per_ray."""
+    import subprocess
+    env = dict(os.environ, RTX_LIB="librtx_count.so")
+    pr = subprocess.run(child_cmd(args, ["--steps", "1", "--warmup", "0"]), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        text=True, timeout=280)
+    if pr.returncode != 0:
+        raise RuntimeError("count run failed: " + pr.stderr[-300:])
+    return json.loads(pr.stdout.strip().splitlines()[-1]).get("gpu_work_per_ray")
+
+
+def useful_flops_per_ray(kernel, work):
+    """SURVEY.md 8d's flop weights (12 per box test, 55 per primitive test) x the kernel's OWN counters (librtx_count.so):
+    k_shadow_coop: a lane tests one child box per node its group visits (`nodes`), then the queued prims' boxes against its own ray
+    (`leaf_entries`); per-lane walks over the 4-wide hierarchy test 4 child boxes per node visit; the octree walks 8 child boxes per
+    node and one box per leaf entry."""
+    if not work:
+        return None
+    cls = "closest" if kernel.startswith("k_closest") else ("shadow" if kernel.startswith("k_shadow") else None)
+    if cls is None:
+        return None
+    w = work[cls]
+    if kernel.startswith("k_shadow_coop"):
+        box = w["nodes"] + w["leaf_entries"]
+    elif kernel in ("k_closest<5>", "k_closest<8>", "k_shadow<6>", "k_shadow<7>"):
+        box = 4.0 * w["nodes"]
+    else:
+        box = 8.0 * w["nodes"] + w["leaf_entries"]
+    return 12.0 * box + 55.0 * w["prim_tests"]
+
+
+def measure(args, pkg, np, torch, out, scene, named, cam, opt, rgba, final, stream, W, H, n_blocks, refl, refr, shadow, gloss, ps, stats, closest_rays):
+    """cpu_baseline + roofline of the N = 1 line (rank 0)."""
+    steps = max(1, args.steps)
+    r0 = stats[-1]
+    names = scene.last_kernel_names()
+    out["kernels"] = names
+    # ---- every kernel ALONE, live: one more frame with RTX_FLAG_SERIAL (HIP events on the launches' own stream)
+    opt_serial = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss, pixel_samples=ps,
+                             rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0, batch_rays=args.batch_rays,
+                             flags=(pkg.abi.FLAG_NO_COOP if args.no_coop else 0) | pkg.abi.FLAG_SERIAL)
+    scene.render_device(cam, opt_serial, rgba.data_ptr(), None, stream, want_stats=True)   # (its own warm-up: first use of the serial path)
+    sa = scene.render_device(cam, opt_serial, rgba.data_ptr(), None, stream, want_stats=True)
+    names_serial = scene.last_kernel_names()
+    n_lights = sum(1 for k in names if k.startswith("shadow"))
+    lc = max(1, sa.launches_closest)
+    alone = {}   # kernel -> [ms per frame alone, launches per frame, rays per frame]
+    alone[names_serial["closest"]] = [sa.ms_closest - sa.ms_shade, lc, float(closest_rays)]
+    alone[names_serial["shade"]] = [sa.ms_shade, lc, float(closest_rays)]
+    for li in range(n_lights):
+        k = names_serial.get("shadow%d" % li, "")
+        if k:
+            e = alone.setdefault(k, [0.0, 0, 0.0])
+            e[0] += sa.ms_shadow_light[li]
+            e[1] += lc
+    shadow_kernels = [k for k in alone if k.startswith("k_shadow")]
+    for k in shadow_kernels:   # feelers per kernel: the launches' share of the frame's shadow launches (exact with one shadow kernel)
+        alone[k][2] = float(r0.rays_shadow) * alone[k][1] / max(1, sum(alone[q][1] for q in shadow_kernels))
+    dominant = max(alone, key=lambda k: alone[k][0])
+    out["kernel_ms_alone_live"] = {k: {"ms_per_frame": v[0], "launches_per_frame": v[1], "ms_per_launch": v[0] / max(1, v[1])} for k, v in alone.items()}
+
+    # ---- CPU baseline: the oracle (literal port of the reference, same 128x8 tile pool) on a bounded sample of the same frame
+    cpu = None
+    if args.cpu_blocks > 0:
+        orc = importlib.import_module("oracle.oracle")   # the checker + CPU baseline, never the product
+        ref_cpus = reference_num_cpus()
+        share = int(os.environ.get("OMP_NUM_THREADS", "0")) or ref_cpus   # the GPU box sets its per-job CPU share here (16)
+        threads = args.cpu_threads or max(1, min(ref_cpus, share))
+        oscene = orc.Scene(named)
+        ocn = orc.Counters()
+        opt_cpu = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
+                              pixel_samples=ps, rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0)
+        picks = sorted({int((k + 0.5) * n_blocks / args.cpu_blocks) for k in range(args.cpu_blocks)})
+        gpu_img = final.cpu().numpy()
+        ok = tot = 0
+        for b in picks:
+            o_rgba, _, cn = oscene.render(cam, opt_cpu, threads=threads, rows=(b * 8, b * 8 + 8), cols=(0, W), want_ids=False)
+            ocn.add(cn)
+            d = np.abs(o_rgba[b * 8:b * 8 + 8, :, :3].astype(np.int32) - gpu_img[b * 8:b * 8 + 8, :, :3].astype(np.int32)).max(axis=-1)
+            ok += int((d <= 1).sum())
+            tot += d.size
+        cpu = {"value": ocn.rays_total / ocn.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "host_cores": os.cpu_count(),
+               "reference_num_cpus": ref_cpus, "kind": "port",
+               "threads_note": "the reference sizes its pool with num_cpus::get() (main.rs:138) = reference_num_cpus; cores = min(that, the job's CPU "
+                               "share OMP_NUM_THREADS=%s)" % os.environ.get("OMP_NUM_THREADS", "unset"),
+               "sample": "tile-block rows %s (8 rows x %d px each) of the same %dx%d frame, same options; %d rays in %.1f s"
+                         % (picks, W, W, H, ocn.rays_total, ocn.seconds)}
+        out["cpu_baseline"] = cpu
+        out["gpu_over_cpu"] = out["value"] / cpu["value"]
+        out["parity_sample"] = {"rgb_within_1": ok / max(1, tot), "pixels": tot}
+
+    # ---- counters of the dominant kernel: collected now, else the committed profile of the same command
+    pmc, pmc_source = None, None
+    os.makedirs(args.profile_dir, exist_ok=True)
+    profile_path = os.path.join(args.profile_dir, "pmc_traffic.json")
+    if args.pmc == "auto":
+        try:
+            raw = collect_pmc(args)
+            pmc = derive_pmc(raw)
+            pmc_source = "live: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE TCC_REQ | SQ_* GRBM_GUI_ACTIVE) on child runs of this command"
+            if args.save_profile:
+                with open(os.path.join(args.profile_dir, "%s_pmc_%s.json" % (args.save_profile, args.workload)), "w") as fh:
+                    json.dump({"command": "bench.py --workload %s --steps 1 --warmup 0 (rocprofv3 --pmc, three passes)" % args.workload,
+                               "passes": {t: c for t, c in PMC_PASSES}, "raw_sums_per_kernel": raw, "derived": pmc}, fh, indent=1)
+                allp = {}
+                try:
+                    allp = json.load(open(profile_path))
+                except (OSError, ValueError):
+                    pass
+                allp["_source"] = ("profiles/<tag>_pmc_<workload>.json (bench.py --save-profile: separate rocprofv3 --pmc passes): bytes per launch = "
+                                   "(FETCH_SIZE x2 + WRITE_SIZE) KB x 1024 / launches; busy = SQ_ACTIVE_INST_VALU x4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)")
+                allp[args.workload] = {"_tag": args.save_profile,   # (the trace kernels; the per-workload file keeps every kernel of the run)
+                                       "kernels": {k: v for k, v in pmc.items() if k.startswith(("k_closest", "k_shade", "k_shadow", "k_generate", "k_resolve", "k_group"))}}
+                json.dump(allp, open(profile_path, "w"), indent=1)
+        except Exception as e:   # noqa: BLE001  (no profiler, a refused pass, a timeout: the committed profile)
+            out["pmc_live_error"] = str(e)[:300]
+    if pmc is None and args.pmc != "off":
+        try:
+            allp = json.load(open(profile_path))
+            pmc = (allp.get(args.workload) or {}).get("kernels")
+            pmc_source = "committed: profiles/pmc_traffic.json[%s] (tag %s), not collected in this run" % (args.workload, (allp.get(args.workload) or {}).get("_tag"))
+        except (OSError, ValueError):
+            pmc = None
+    work = out.get("gpu_work_per_ray")
+    if work is None and args.pmc != "off":
+        try:
+            work = count_work(args)
+            out["gpu_work_per_ray"] = work
+        except Exception as e:   # noqa: BLE001
+            out["count_work_error"] = str(e)[:300]
+
+    v = (pmc or {}).get(dominant)
+    ms_alone, launches, nrays = alone[dominant]
+    avg_alone_ms = ms_alone / max(1, launches)
+    # the same kernel's average launch in the TIMED region (with overlap: a duration under sharing)
+    if dominant.startswith("k_shadow"):
+        li_of = [li for li in range(n_lights) if names.get("shadow%d" % li) == dominant]
+        timed_ms = sum(sum(st.ms_shadow_light[li] for li in li_of) for st in stats) / steps / max(1, len(li_of) * max(1, r0.launches_closest))
+    elif dominant.startswith("k_shade"):
+        timed_ms = sum(st.ms_shade for st in stats) / steps / max(1, r0.launches_closest)
+    else:
+        timed_ms = sum(st.ms_closest - st.ms_shade for st in stats) / steps / max(1, r0.launches_closest)
+    roof = {"kernel": dominant, "avg_launch_ms": timed_ms, "avg_launch_ms_alone": avg_alone_ms, "launches_per_frame": launches,
+            "rays_per_launch": nrays / max(1, launches), "overlap": not args.serial, "source": pmc_source}
+    if v:
+        valu_frac = v["busy"] * v["lane_utilisation"]
+        hbm_frac = v["hbm_gbs_alone"] / HBM_PEAK_GBS
+        bound = "valu" if valu_frac >= hbm_frac else "hbm"
+        roof.update({
+            "bound": bound, "frac": valu_frac if bound == "valu" else hbm_frac,
+            "achieved": valu_frac * VALU_LANE_SLOTS if bound == "valu" else v["hbm_gbs_alone"],
+            "peak": VALU_LANE_SLOTS if bound == "valu" else HBM_PEAK_GBS,
+            "unit": "VALU lane-slots per cycle doing a lane's work (256 CUs x 4 SIMDs x 16 lanes)" if bound == "valu" else "GB/s",
+            "valu_frac": valu_frac, "valu_busy": v["busy"], "lane_utilisation": v["lane_utilisation"],
+            "valu_insts_per_wave": v["valu_insts_per_wave"], "waves_waiting_frac": v.get("waves_waiting_frac"),
+            "hbm_frac": hbm_frac, "l2_frac": v["l2_request_gbs"] / L2_PEAK_GBS, "hbm_gbs_alone": v["hbm_gbs_alone"],
+            "l2_request_gbs": v["l2_request_gbs"], "l2_hit_rate": v.get("l2_hit_rate"),
+            "traffic": v["hbm_bytes_per_launch"], "traffic_write": v.get("hbm_write_bytes_per_launch"),
+            "avg_launch_ms_alone_profiled": v["alone_ms_per_launch"],
+            # the committed profile describes another build if its launch time is far from what this run measures
+            "profile_matches_this_run": abs(v["alone_ms_per_launch"] - avg_alone_ms) <= 0.15 * max(avg_alone_ms, 1e-9)})
+    else:
+        roof.update({"bound": None, "frac": None, "achieved": None, "peak": None, "unit": None, "traffic": None})
+    fpr = useful_flops_per_ray(dominant, work)
+    if fpr is not None and avg_alone_ms > 0:
+        tflops = fpr * (nrays / max(1, launches)) / (avg_alone_ms * 1e-3) / 1e12
+        roof.update({"useful_flop_per_ray": fpr, "useful_tflops": tflops, "useful_flop_frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                     "useful_flop_peak_tflops": FP64_VALU_PEAK_TFLOPS})
+    if cpu is not None:   # SURVEY.md 8d's byte model: reference-order algorithmic bytes the kernels avoid touching; never a roofline fraction
+        is_shadow = dominant.startswith("k_shadow")
+        bpr = (ocn.algorithmic_bytes(1) / max(1, ocn.rays[4])) if is_shadow else (ocn.algorithmic_bytes(0) / max(1, ocn.rays_closest))
+        roof["algorithmic_bytes_per_ray_reference_order"] = bpr
+        roof["work_avoidance_vs_reference_order"] = bpr * (nrays / max(1, launches)) / (avg_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roof["note"] = ("dominant kernel = the largest share of the frame's kernel time, every kernel timed ALONE (one extra RTX_FLAG_SERIAL frame, HIP "
+                    "events on the launch's own stream); bound = the larger of valu_frac (VALU busy x lanes active per VALU instruction: issue "
+                    "slots doing a lane's work) and hbm_frac (measured HBM bytes / launch time / 8 TB/s); useful_flop_frac = SURVEY 8d flop "
+                    "weights x the kernel's own traversal counters (librtx_count.so) / launch time alone / 78.6 TFLOP/s FP64 vector peak: the "
+                    "share of the machine doing the ALGORITHM's arithmetic; work_avoidance_vs_reference_order is SURVEY 8d's byte model "
+                    "(what the reference's unordered walk would move), > 1 because the kernels do not move those bytes")
+    out["roofline"] = roof
 
 
 def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, scene_name, W, H, fov, refl, refr, shadow, gloss, ps):

@@ -164,7 +164,8 @@ pub struct RtxStats {
     pub peak_pool_rays: u64,
     pub work: [[u64; 3]; 2],
     pub exact_shadow_rerenders: u64,
-    pub reserved: [u64; 1],
+    pub ms_shade: f64,
+    pub ms_shadow_light: [f64; 16],
 }
 
 #[repr(C)]
@@ -214,6 +215,7 @@ extern "C" {
     pub fn rtx_shade_probe(scene: *mut RtxScene, which: i32, n: i64, input: *const f64, out: *mut f64) -> RtxStatus;
     pub fn rtx_octree_dump(desc: *const RtxSceneDesc, depth: *mut i32, n_nodes: *mut i64, n_entries: *mut i64,
                            bbox_out: *mut f64, shape_out: *mut i32, entries_out: *mut i32) -> RtxStatus;
+    pub fn rtx_last_kernel_names(scene: *const RtxScene, out: *mut c_char, cap: i64) -> RtxStatus;
     pub fn rtx_hierarchy_dump(scene: *mut RtxScene, which: i32, out: *mut c_void, cap_bytes: i64, n_bytes: *mut i64) -> RtxStatus;
     pub fn rtx_strerror(status: RtxStatus) -> *const c_char;
     pub fn rtx_last_error() -> *const c_char;

@@ -206,7 +206,7 @@ typedef struct rtx_stats {
     uint64_t rays_shadow;     /* shadow tries (renderer.rs:198) */
     double ms_total;          /* wall time of the call, host clock */
     double ms_device;         /* first kernel start -> last kernel end, HIP events */
-    double ms_closest;        /* sum of trace_closest+shade kernel durations, HIP events */
+    double ms_closest;        /* sum of the durations of the closest-hit + shading chains (one per wavefront step), HIP events */
     double ms_shadow;         /* sum of trace_shadow kernel durations, HIP events */
     uint32_t launches_closest;
     uint32_t launches_shadow;
@@ -217,7 +217,9 @@ typedef struct rtx_stats {
     uint64_t work[2][3];
     uint64_t exact_shadow_rerenders;   /* 1 if a shadow launch met more degenerate feelers than its retry list holds and the frame
                                           was therefore rendered again with all-f64 shadow walks ("Degenerate rays") */
-    uint64_t reserved[1];
+    double ms_shade;          /* the part of ms_closest spent in the shading launches (queue-slot scan + k_shade): ms_closest - ms_shade
+                                 = the closest-hit kernels (HIP events on the launches' own stream) */
+    double ms_shadow_light[16];   /* ms_shadow split by light: lights of different kinds / try counts run different kernels */
 } rtx_stats;
 
 typedef struct rtx_scene_info {
@@ -342,6 +344,11 @@ rtx_status rtx_octree_dump(const rtx_scene_desc *desc, int32_t *depth, int64_t *
  * made when out != NULL and cap_bytes >= that size.  tests/test_gpu_build.py compares the device-side builder's arrays with the
  * host builder's (RTX_BUILD_HIERARCHY=host|device). */
 rtx_status rtx_hierarchy_dump(rtx_scene *scene, int32_t which, void *out, int64_t cap_bytes, int64_t *n_bytes);
+
+/* Measurement aid, no counterpart in the reference: the kernels the scene's LAST render call launched, by the names rocprofv3 prints,
+ * as "closest=k_closest<5>;shade=k_shade<true>;shadow0=k_shadow_coop<false>;shadow1=..." (one shadowN per light; empty before the
+ * first render).  bench.py uses it to attribute counter passes and launch times to the kernel that actually ran. */
+rtx_status rtx_last_kernel_names(const rtx_scene *scene, char *out, int64_t cap);
 
 const char *rtx_strerror(rtx_status status);
 /* Last error text recorded by this thread (HIP error strings, limit details). Never NULL. */

@@ -102,7 +102,7 @@ class Stats(C.Structure):
         ("ms_closest", C.c_double), ("ms_shadow", C.c_double),
         ("launches_closest", C.c_uint32), ("launches_shadow", C.c_uint32),
         ("peak_pool_rays", C.c_uint64), ("work", (C.c_uint64 * 3) * 2), ("exact_shadow_rerenders", C.c_uint64),
-        ("reserved", C.c_uint64 * 1),
+        ("ms_shade", C.c_double), ("ms_shadow_light", C.c_double * 16),
     ]
 
     @property
@@ -125,7 +125,7 @@ class SceneInfo(C.Structure):
 # every symbol include/rtx.h declares
 EXPORTS = (
     "rtx_scene_create", "rtx_scene_destroy", "rtx_scene_get_info", "rtx_render",
-    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_shade_probe", "rtx_octree_dump", "rtx_hierarchy_dump", "rtx_strerror",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_nearest_hits", "rtx_nearest_hits_ex", "rtx_shadow_products", "rtx_shadow_products_ex", "rtx_shade_probe", "rtx_octree_dump", "rtx_hierarchy_dump", "rtx_last_kernel_names", "rtx_strerror",
     "rtx_last_error", "rtx_version",
 )
 
@@ -173,6 +173,8 @@ def load():
     lib.rtx_octree_dump.restype = C.c_int32
     lib.rtx_hierarchy_dump.argtypes = [vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.rtx_hierarchy_dump.restype = C.c_int32
+    lib.rtx_last_kernel_names.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.rtx_last_kernel_names.restype = C.c_int32
     lib.rtx_strerror.argtypes = [C.c_int32]
     lib.rtx_strerror.restype = C.c_char_p
     lib.rtx_last_error.argtypes = []

@@ -350,6 +350,9 @@ rtx_status flatten(const rtx_scene_desc *d, Flat &fl) {
             if (d->skybox_image[f] < 0 || d->skybox_image[f] >= d->n_images) return fail(RTX_ERR_INVALID_ARGUMENT, "skybox image out of range");
 
     std::vector<uint8_t> seen_s((size_t)d->n_spheres, 0), seen_p((size_t)d->n_planes, 0), seen_t((size_t)d->n_triangles, 0);
+    fl.fin_kind.reserve((size_t)d->n_spheres + (size_t)d->n_triangles);
+    fl.fin_index.reserve((size_t)d->n_spheres + (size_t)d->n_triangles);
+    fl.oct.prim_box.reserve((size_t)d->n_spheres + (size_t)d->n_triangles);
     for (long long k = 0; k < total; ++k) {
         int kind, idx;
         if (d->order_kind) { kind = d->order_kind[k]; idx = d->order_index[k]; }
@@ -428,6 +431,9 @@ struct rtx_scene {
     int64_t n_wide_nodes = 0, n_bvh4_nodes = 0;   // sizes of d.wide / d.bvh4 as built (rtx_hierarchy_dump)
     const DWideChild *wide_built = nullptr;       // (d.wide / d.bvh4 are cleared when a walk cannot use them; the dump shows what was built)
     const DNode4 *bvh4_built = nullptr;
+    // what the last render call launched (rtx_last_kernel_names)
+    RtxTraceNames last_trace;
+    const char *last_shadow[RTX_MAX_LIGHTS] = {};
     Work w;
 };
 
@@ -819,7 +825,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         *e = w.events[ev_used++];
         return RTX_OK;
     };
-    struct Span { hipEvent_t a, b; int kind; };
+    struct Span { hipEvent_t a, b; int kind; hipEvent_t mid; };   // kind 0: closest-hit + shading chain (mid: between the two), 1 + light: a shadow launch
     std::vector<Span> spans;
     const bool timing = stats != nullptr && !noalloc;
 
@@ -904,14 +910,14 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             w.h_up->overflow = 0;
             HIPCHECK(hipMemcpyAsync(v.d_counters, w.h_up, offsetof(DCounters, ray_slots), hipMemcpyHostToDevice, stream));
         }
-        Span sp_c{nullptr, nullptr, 0};
+        Span sp_c{nullptr, nullptr, 0, nullptr};
         if (timing) {
-            if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b))) return st;
+            if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b)) || (st = next_event(&sp_c.mid))) return st;
             HIPCHECK(hipEventRecord(sp_c.a, stream));
         }
         const DShadowQ &sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
-                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, v.group_base);
+                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, &s->last_trace);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));
@@ -934,12 +940,12 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             for (size_t li = 0; li < s->lights.size(); ++li) {
                 uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194
                 hipStream_t sstream = overlap ? w.aux[li % n_aux] : stream;
-                Span sp_s{nullptr, nullptr, 1};
+                Span sp_s{nullptr, nullptr, 1 + (int)li, nullptr};
                 if (timing) {   // one event pair per launch, so ms_shadow / launches_shadow is a kernel duration
                     if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
                     HIPCHECK(hipEventRecord(sp_s.a, sstream));
                 }
-                rtxk_shadow(sstream, s->d, fr, sq, (uint32_t)li, n, tries, v.d_counters, v.acc);
+                s->last_shadow[li] = rtxk_shadow(sstream, s->d, fr, sq, (uint32_t)li, n, tries, v.d_counters, v.acc);
                 ++launches_shadow;
                 if (timing) {
                     HIPCHECK(hipEventRecord(sp_s.b, sstream));
@@ -1023,6 +1029,11 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             for (const Span &sp : spans) {
                 HIPCHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
                 (sp.kind == 0 ? stats->ms_closest : stats->ms_shadow) += ms;
+                if (sp.kind > 0) stats->ms_shadow_light[sp.kind - 1] += ms;
+                if (sp.mid) {
+                    HIPCHECK(hipEventElapsedTime(&ms, sp.mid, sp.b));
+                    stats->ms_shade += ms;
+                }
             }
         }
         stats->launches_closest = launches_closest;
@@ -1375,6 +1386,16 @@ rtx_status rtx_scene_destroy(rtx_scene *s) {
 rtx_status rtx_scene_get_info(const rtx_scene *s, rtx_scene_info *info) {
     if (!s || !info) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
     *info = s->info;
+    return RTX_OK;
+}
+
+rtx_status rtx_last_kernel_names(const rtx_scene *s, char *out, int64_t cap) {
+    if (!s || !out || cap <= 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_last_kernel_names: bad argument");
+    std::string t = std::string("closest=") + s->last_trace.closest + ";shade=" + s->last_trace.shade;
+    for (size_t li = 0; li < s->lights.size(); ++li)
+        t += ";shadow" + std::to_string(li) + "=" + (s->last_shadow[li] ? s->last_shadow[li] : "");
+    if ((int64_t)t.size() + 1 > cap) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_last_kernel_names: buffer too small");
+    std::memcpy(out, t.c_str(), t.size() + 1);
     return RTX_OK;
 }
 

@@ -220,11 +220,16 @@ struct hipStreamOpaque;
 typedef void *rtx_stream_t;
 
 void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count);
+// (names: what was launched, as rocprofv3 prints it, e.g. "k_closest<5>": rtx_last_kernel_names, for the measurement harness)
+struct RtxTraceNames { const char *closest = ""; const char *shade = ""; };
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */,
-                uint32_t *group_base /* [2 * ceil(count / RTX_BLOCK)]: workgroup counts, then their exclusive scan */);
-void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+                void *record_after_closest /* hipEvent_t or NULL: recorded between the closest-hit launches and the shading launches (timing) */,
+                uint32_t *group_base /* [2 * ceil(count / RTX_BLOCK)]: workgroup counts, then their exclusive scan */,
+                RtxTraceNames *names = nullptr);
+// returns the name of the kernel that does the launch's work ("" when nothing was launched)
+const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);
 void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *direction,

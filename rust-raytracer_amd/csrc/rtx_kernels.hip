@@ -3011,8 +3011,14 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 }
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
-                void *wait_before_shade, void *wait_before_shade2, uint32_t *group_base) {
+                void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, RtxTraceNames *names) {
     if (count == 0) return;
+    RtxTraceNames nm;
+    static_assert(MODE_CLOSEST == 0 && MODE_CLOSEST_REF == 1 && MODE_CLOSEST_BVH == 5 && MODE_CLOSEST_BVH_DEALT == 8, "the kernel names below");
+    nm.closest = (fr.flags & RTX_FLAG_REFERENCE_ORDER) ? "k_closest<1>"
+                 : ((sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK)) ? (sc.all_opaque ? "k_closest<5>" : "k_closest<8>") : "k_closest<0>");
+    nm.shade = (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE)) ? "k_shade<true>" : "k_shade<false>";
+    if (names) *names = nm;
     const bool want_groups = fr.shadow_samples != 0u && sc.n_lights > 0;   // the slots of the compact shadow queue
     const unsigned nb = grid_for(count);
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER) {
@@ -3035,6 +3041,7 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
         hipLaunchKernelGGL(k_closest_retry, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
                            hit_ref, want_groups ? group_base : nullptr);
     }
+    if (record_after_closest) (void)hipEventRecord((hipEvent_t)record_after_closest, (hipStream_t)stream);
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
     if (want_groups)   // (after the waits: it writes the queue's group count)
@@ -3046,9 +3053,9 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
         hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
                            hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));
 }
-void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
-                 uint32_t tries, DCounters *counters, double *acc) {
-    if (n_groups == 0 || tries == 0) return;
+const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
+                        uint32_t tries, DCounters *counters, double *acc) {
+    if (n_groups == 0 || tries == 0) return "";
     uint32_t pow2 = (tries <= 64u && (tries & (tries - 1u)) == 0u) ? 1u : 0u;
     uint64_t lanes = (uint64_t)n_groups * tries;
     // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
@@ -3061,6 +3068,15 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
     // the any-hit kernels hand degenerate feelers to k_shadow_retry, the two-phase product those it cannot answer
     const bool any_hit = (sc.all_opaque != 0 && !exact) || product_bvh;
     if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap), 0, sizeof(uint32_t), (hipStream_t)stream);
+    // the name of the kernel the chain below picks for the launch's work (the same conditions, in the same order)
+    static_assert(MODE_ANY == 2 && MODE_PRODUCT == 3 && MODE_PRODUCT_FAST == 4 && MODE_ANY_BVH == 6 && MODE_PRODUCT_BVH == 7, "the kernel names below");
+    const char *name = exact ? "k_shadow<3>"
+                       : (coop && tries % 16u == 0u) ? "k_shadow_coop<false>"
+                       : (coop && (tries == 4u || tries == 8u)) ? "k_shadow_coop<true>"
+                       : (sc.all_opaque && bvh) ? "k_shadow<6>"
+                       : sc.all_opaque ? "k_shadow<2>"
+                       : (fr.flags & RTX_FLAG_REFERENCE_ORDER) ? "k_shadow<3>"
+                       : product_bvh ? "k_shadow<7>" : "k_shadow<4>";
     if (exact)   // the all-f64 product walk answers every feeler, degenerate or not (all-opaque scenes: a product of zeros)
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc, nullptr);
@@ -3096,6 +3112,7 @@ void rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShado
                            n_groups, tries, pow2, counters, acc, nullptr);
     if (any_hit)
         hipLaunchKernelGGL(k_shadow_retry, dim3(64), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, tries, acc);
+    return name;
 }
 __global__ void k_set_pool_tail(DCounters *counters, uint32_t pool_tail) {
     counters->pool_tail = pool_tail;

@@ -38,6 +38,12 @@ class Scene:
         abi.check(self._lib.rtx_scene_get_info(self.h, C.byref(inf)), "rtx_scene_get_info")
         return inf
 
+    def last_kernel_names(self):
+        """rtx_last_kernel_names as a dict: {"closest": "k_closest<5>", "shade": ..., "shadow0": ..., ...}."""
+        buf = C.create_string_buffer(1024)
+        abi.check(self._lib.rtx_last_kernel_names(self.h, buf, 1024), "rtx_last_kernel_names")
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if "=" in kv)
+
     def hierarchy_dump(self):
         """rtx_hierarchy_dump: the SAH hierarchy as it lies on the device: (wide, bvh4) structured numpy arrays
         (wide[n, 16] of DWideChild, bvh4[n] of DNode4; empty arrays where a cut was not built)."""

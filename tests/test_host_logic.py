@@ -31,7 +31,7 @@ def test_struct_sizes_match_header(rtx):
     assert ctypes.sizeof(a.Light) == 8 + 7 * 8
     assert ctypes.sizeof(a.Camera) == 10 * 8 + 8
     assert ctypes.sizeof(a.Options) == 56
-    assert ctypes.sizeof(a.Stats) == 5 * 8 + 4 * 8 + 8 + 8 + 48 + 16
+    assert ctypes.sizeof(a.Stats) == 5 * 8 + 4 * 8 + 8 + 8 + 48 + 8 + 8 + 16 * 8      # + exact_shadow_rerenders, ms_shade, ms_shadow_light[16]
 
 
 @pytest.mark.parametrize("which", ["sphere", "cornell", "mesh", "cube", "empty", "mesh_big"])

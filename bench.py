@@ -144,19 +144,25 @@ def main():
     build_warm_s = time.time() - t0
 
     n_blocks = H // 8
-    rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    # every rank renders ONLY its own 8-row blocks, packed (RTX_FLAG_COMPACT_OUTPUT), straight into the buffer the gather sends:
+    # H/N rows per rank instead of a full frame, no pack step
     gat = pkg.sharding.StillGather(W, H, rank, world, comm_dev)
     final = gat.final
+    target = gat.target if comm_dev is dev else torch.zeros_like(gat.target, device=dev)
+    rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)    # full-frame buffer of measure()'s single-GPU extra frames
 
+    base_flags = (pkg.abi.FLAG_NO_COOP if args.no_coop else 0) | (pkg.abi.FLAG_SERIAL if args.serial else 0)
     opt = pkg.options(reflect_depth=refl, refract_depth=refr, shadow_samples=shadow, gloss_samples=gloss,
                       pixel_samples=ps, rng_mode=pkg.abi.RNG_PHILOX, seed=0, frame=0,
                       shard_index=rank, shard_count=world, batch_rays=args.batch_rays,
-                      flags=(pkg.abi.FLAG_NO_COOP if args.no_coop else 0) | (pkg.abi.FLAG_SERIAL if args.serial else 0))
+                      flags=base_flags | pkg.abi.FLAG_COMPACT_OUTPUT)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        st = scene.render_device(cam, opt, rgba.data_ptr(), None, stream, want_stats=True)
-        gat.gather(rgba if comm_dev is dev else rgba.cpu(), dist)   # RCCL over xGMI: <= 1.04 MB per rank at 1080p (a copy at N=1)
+        st = scene.render_device(cam, opt, target.data_ptr(), None, stream, want_stats=True)
+        if comm_dev is not dev:
+            gat.target.copy_(target)                                # gloo rehearsal: the collective runs on host tensors
+        gat.gather(dist)                                            # RCCL over xGMI: <= 1.04 MB per rank at 1080p (a de-interleave at N=1)
         return st
 
     def barrier():
@@ -605,6 +611,13 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
         agg = summed
         agg[5] = tmax[0]
     agg = agg.cpu().numpy()
+    mine_ms = torch.tensor([sum(ms_call) / max(1, len(ms_call))], dtype=torch.float64, device=comm_dev)   # this rank's mean frame (call) time
+    if world > 1:
+        all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
+        per_rank = [float(t.item()) for t in all_ms]
+    else:
+        per_rank = [float(mine_ms.item())]
     total_rays, elapsed = float(agg[:5].sum()), float(agg[5])
     rounds = math.ceil(len(frames) / world)
     if rank == 0:
@@ -613,7 +626,7 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
                "steps": rounds, "warmup": args.warmup, "ms_per_step": elapsed / rounds * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s camera animation %g-%g s at %g fps: %d frames of %dx%d, pixel_samples %d (%d spp), shadow_samples %d, "
-                                      "reflect %d refract %d, frame k on rank k %% %d, one gather per round of %d frames to rank 0; procedural "
+                                      "reflect %d refract %d, frame k on rank k %% %d, one gather per round of %d frames to rank 0 overlapped with the next round's render; procedural "
                                       "stand-in mesh (reference assets absent), philox seed 0" %
                                       (scene_name, args.time_slice[0], args.time_slice[1], args.fps, len(frames), W, H, ps, ps * ps, shadow,
                                        refl, refr, world, world),
@@ -621,7 +634,8 @@ def animate(args, pkg, torch, dist, np, world, rank, local_rank, dev, comm_dev, 
                "frames": len(frames), "frames_rank0": int(n_mine), "ms_per_frame_node": elapsed / len(frames) * 1e3,
                "ms_per_frame_rank0_device": sum(ms_dev) / max(1, len(ms_dev)),
                "ms_per_frame_rank0_call": sum(ms_call) / max(1, len(ms_call)), "frames_per_s_node": len(frames) / elapsed,
-               "rays_per_frame": total_rays / len(frames), "last_frame_gathered": last.get("k")}
+               "rays_per_frame": total_rays / len(frames), "last_frame_gathered": last.get("k"),
+               "per_rank_frame_ms": {"min": min(per_rank), "max": max(per_rank), "by_rank": [round(x, 3) for x in per_rank]}}
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

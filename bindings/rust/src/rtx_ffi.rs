@@ -33,6 +33,7 @@ pub const RTX_FLAG_REFERENCE_ORDER: u32 = 1;
 pub const RTX_FLAG_NO_COOP: u32 = 2;
 pub const RTX_FLAG_SERIAL: u32 = 4;
 pub const RTX_FLAG_OCTREE_WALK: u32 = 8;
+pub const RTX_FLAG_COMPACT_OUTPUT: u32 = 16;
 pub const RTX_PROBE_FRESNEL: i32 = 0;
 pub const RTX_PROBE_REFRACT: i32 = 1;
 pub const RTX_PROBE_REFLECT: i32 = 2;

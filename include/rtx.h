@@ -178,6 +178,11 @@ typedef struct rtx_options {
 } rtx_options;
 
 enum {
+    RTX_FLAG_COMPACT_OUTPUT = 16, /* rtx_render_device* only: rgba_out_dev / primary_prim_id_out_dev hold ONLY the call's own 8-row blocks
+                                    (shard_index, shard_index + shard_count, ...), packed in that order: ceil((H/8 - shard_index) /
+                                    shard_count) * 8 rows of image_width pixels, instead of a full frame with the other ranks' rows
+                                    untouched.  The multi-GPU still gather (`Surface::merge`, surface.rs:83-94) sends this
+                                    buffer as it is. */
     RTX_FLAG_OCTREE_WALK = 8,    /* the per-lane closest-hit and any-hit walks run over the reference's octree (conservative f32
                                     twins of its nodes and leaf entries) instead of the 4-wide SAH hierarchy built beside it (A/B
                                     measurements and tests: both reach a superset of the prims a ray truly hits and decide each

@@ -23,6 +23,7 @@ FLAG_REFERENCE_ORDER = 1
 FLAG_NO_COOP = 2
 FLAG_SERIAL = 4
 FLAG_OCTREE_WALK = 8
+FLAG_COMPACT_OUTPUT = 16
 PROBE_FRESNEL, PROBE_REFRACT, PROBE_REFLECT, PROBE_MATERIAL, PROBE_TEXTURE, PROBE_SKYBOX, PROBE_BBOX = range(7)
 
 c_double_p = C.POINTER(C.c_double)

@@ -1424,6 +1424,7 @@ rtx_status rtx_render_device_noalloc(rtx_scene *s, const rtx_camera *cam, const 
 rtx_status rtx_render(rtx_scene *s, const rtx_camera *cam, const rtx_options *opt, uint8_t *rgba_out,
                       int32_t *primary_prim_id_out, rtx_stats *stats) {
     if (!s || !cam || !opt || !rgba_out) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (opt->flags & RTX_FLAG_COMPACT_OUTPUT) return fail(RTX_ERR_INVALID_ARGUMENT, "RTX_FLAG_COMPACT_OUTPUT is for rtx_render_device (device buffers) only");
     HIPCHECK(hipSetDevice(s->device));
     size_t n_pix = (size_t)cam->image_width * cam->image_height;
     Work &w = s->w;

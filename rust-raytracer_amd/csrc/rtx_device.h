@@ -194,7 +194,7 @@ struct DShadowQ {
 // internal bit: k_shade's small instance (see the kernel): set by the host for frames whose shadow feelers run in the cooperative kernel
 // beside the closest-hit / shade chain
 #define RTX_FLAG_INTERNAL_SMALL_SHADE 0x40000000u
-#define RTX_FLAG_PUBLIC_MASK 0xFu
+#define RTX_FLAG_PUBLIC_MASK 0x1Fu
 
 struct DCounters {
     uint32_t pool_tail;

@@ -1559,6 +1559,13 @@ DEV bool decode_sample(const DFrame &fr, uint32_t s, uint32_t *px, uint32_t *row
     return *px < fr.W && *row < fr.H;
 }
 
+// the row of an output buffer that holds image row `row` (row 0 = top): the row itself, or with RTX_FLAG_COMPACT_OUTPUT its place among
+// the shard's own 8-row blocks
+DEV uint32_t out_row(const DFrame &fr, uint32_t row) {
+    if (!(fr.flags & RTX_FLAG_COMPACT_OUTPUT)) return row;
+    return ((row >> 3) - fr.shard_index) / fr.shard_count * 8u + (row & 7u);
+}
+
 DEV void pool_store(const DPool &pool, uint32_t slot, V3 o, V3 d, V3 thr, uint64_t key, uint32_t sample, uint32_t flags) {
     size_t cap = pool.cap;
     double *f = pool.f + slot;
@@ -1898,7 +1905,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     if (valid && type == RAY_PRIMARY && prim_id_out) {
         uint32_t px, row, sub;
         decode_sample(fr, sample, &px, &row, &sub);
-        if (sub == 0u) prim_id_out[(size_t)row * fr.W + px] = is_hit ? prim_id : -1;
+        if (sub == 0u) prim_id_out[(size_t)out_row(fr, row) * fr.W + px] = is_hit ? prim_id : -1;
     }
 
     // ---- miss: skybox / background (renderer.rs:139-144)
@@ -2875,7 +2882,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_resolve(DFrame fr, const double *
         q[ch] = (uint8_t)iv;
     }
     out.x = q[0]; out.y = q[1]; out.z = q[2]; out.w = 255;
-    *reinterpret_cast<uchar4 *>(rgba_out + ((size_t)row * fr.W + px) * 4) = out;
+    *reinterpret_cast<uchar4 *>(rgba_out + ((size_t)out_row(fr, row) * fr.W + px) * 4) = out;
 }
 
 // Probe kernels behind rtx_nearest_hits / rtx_shadow_products

@@ -3,11 +3,16 @@
 
 Stills:     the frame is cut into blocks of 8 rows (the reference's tile height, renderer.rs:42);
             block b belongs to rank b % world (interleaved for load balance).  Each rank renders its
-            blocks with rtx_options.shard_index/shard_count, packs them into a compact buffer and
-            ONE gather brings them to rank 0, which de-interleaves them into the final Surface —
-            the counterpart of Surface::merge (compositor/surface.rs:83-94).
+            blocks with rtx_options.shard_index/shard_count and RTX_FLAG_COMPACT_OUTPUT straight into a
+            compact buffer of ceil(H/8/world) blocks (StillGather.target), and ONE gather brings the
+            compact buffers to rank 0, which de-interleaves them into the final Surface — the
+            counterpart of Surface::merge (compositor/surface.rs:83-94).
 Animations: frame k belongs to rank k % world (animator.rs:44-48 renders frames independently);
-            each finished frame is gathered to rank 0 in rounds of `world` frames.
+            the finished frames of a round of `world` frames travel to rank 0 in ONE gather (the
+            "this rank had a frame" flag rides in a 16-byte trailer of the frame buffer), and the
+            gather of round r runs while round r + 1 renders (FrameGather: two send and two receive
+            buffers, allocated once) — as the reference overlaps its PPM writer thread with the next
+            frame's render (animator.rs:27-42).
 
 The RNG is keyed on absolute pixel / frame numbers, so the image does not depend on `world`.
 Nothing here touches the oracle; the functions work on CPU tensors too (that is what the gloo
@@ -27,7 +32,11 @@ def frames_of_rank(total_frames, rank, world):
 
 
 class StillGather:
-    """Pre-allocated buffers for gathering an interleaved still to rank 0."""
+    """Pre-allocated buffers for gathering an interleaved still to rank 0.
+
+    `target` ([max_blocks * 8, W, 4] uint8 on `device`) is what the rank renders into with
+    RTX_FLAG_COMPACT_OUTPUT: its own blocks, packed.  gather(dist) sends it as it is; gather(dist, rgba=full_frame)
+    packs the rank's blocks out of a full-size frame first (callers that rendered without the flag)."""
 
     def __init__(self, width, height, rank, world, device):
         assert height % 8 == 0, "image_height must be a multiple of 8 (renderer.rs:73)"
@@ -37,45 +46,87 @@ class StillGather:
         self.mine = blocks_of_rank(height, rank, world)
         self.max_blocks = (self.n_blocks + world - 1) // world
         self.compact = torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
+        self.target = self.compact.view(self.max_blocks * 8, width, 4)
         self.idx = torch.tensor(self.mine, dtype=torch.long, device=device)
         self.parts = ([torch.zeros_like(self.compact) for _ in range(world)]
                       if (world > 1 and rank == 0) else None)
         self.final = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if rank == 0 else None
 
-    def gather(self, rgba, dist=None):
-        """rgba: this rank's [H, W, 4] uint8 frame (only its own blocks need to be valid).
-        Returns the assembled frame on rank 0, None elsewhere."""
-        if self.world == 1:
-            self.final.copy_(rgba)
-            return self.final
-        blocks = rgba.view(self.n_blocks, self.row_bytes)
-        if self.mine:
-            self.compact[:len(self.mine)] = blocks.index_select(0, self.idx)
-        dist.gather(self.compact, self.parts, dst=0)
-        if self.rank != 0:
-            return None
+    def gather(self, dist=None, rgba=None):
+        """Returns the assembled frame on rank 0, None elsewhere."""
+        if rgba is not None and self.mine:
+            self.compact[:len(self.mine)] = rgba.view(self.n_blocks, self.row_bytes).index_select(0, self.idx)
+        if self.world > 1:
+            dist.gather(self.compact, self.parts, dst=0)
+            if self.rank != 0:
+                return None
         out = self.final.view(self.n_blocks, self.row_bytes)
         for r in range(self.world):
             n = len(range(r, self.n_blocks, self.world))
             if n:
-                out[r::self.world] = self.parts[r][:n]
+                out[r::self.world] = (self.parts[r] if self.world > 1 else self.compact)[:n]
         return self.final
 
 
+class FrameGather:
+    """One gather per round of an animation, pipelined one round deep.
+
+    Every rank owns two send buffers, rank 0 two sets of `world` receive buffers (allocated once: 2 x world x (H*W*4 + 16) bytes).
+    submit(frame or None) copies the rank's finished frame into the round's send buffer (its last 16 bytes carry the "have a
+    frame" flag) and starts the round's gather asynchronously; it first completes the PREVIOUS round's gather and returns that
+    round's frames on rank 0 ([tensor or None] per rank, valid until the round after next overwrites them), so the transfer of
+    round r overlaps the rendering of round r + 1.  flush() completes the last round."""
+
+    TRAILER = 16
+
+    def __init__(self, height, width, rank, world, device, dist):
+        self.H, self.W, self.rank, self.world, self.dist = height, width, rank, world, dist
+        self.nbytes = height * width * 4
+        self.send = [torch.zeros(self.nbytes + self.TRAILER, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = ([[torch.zeros_like(self.send[0]) for _ in range(world)] for _ in range(2)]
+                     if (world > 1 and rank == 0) else None)
+        self.round = 0
+        self.pending = None      # (work handle or None, buffer index)
+
+    def _complete(self):
+        if self.pending is None:
+            return None
+        work, b = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        if self.rank != 0:
+            return None
+        bufs = self.recv[b] if self.world > 1 else [self.send[b]]
+        # one host read for the round's flags (the frames stay where they are)
+        flags = torch.stack([p[self.nbytes] for p in bufs]).cpu().tolist()
+        return [p[:self.nbytes].view(self.H, self.W, 4) if f else None for p, f in zip(bufs, flags)]
+
+    def submit(self, frame):
+        done = self._complete()
+        b = self.round & 1
+        buf = self.send[b]
+        if frame is not None:
+            buf[:self.nbytes].copy_(frame.reshape(-1))
+        buf[self.nbytes:].fill_(1 if frame is not None else 0)
+        work = None
+        if self.world > 1:
+            work = self.dist.gather(buf, self.recv[b] if self.rank == 0 else None, dst=0, async_op=True)
+        self.pending = (work, b)
+        self.round += 1
+        return done
+
+    def flush(self):
+        return self._complete()
+
+
 def gather_frames(frame, have_frame, rank, world, dist):
-    """One round of the animation gather: every rank passes its finished frame ([H, W, 4] uint8) or
-    a dummy of the same shape with have_frame=False; rank 0 gets the list of the round's frames
-    in rank order (None where a rank had none)."""
-    if world == 1:
-        return [frame if have_frame else None]
-    flag = torch.tensor([1 if have_frame else 0], dtype=torch.uint8, device=frame.device)
-    parts = [torch.zeros_like(frame) for _ in range(world)] if rank == 0 else None
-    flags = [torch.zeros_like(flag) for _ in range(world)] if rank == 0 else None
-    dist.gather(frame, parts, dst=0)
-    dist.gather(flag, flags, dst=0)
-    if rank != 0:
-        return None
-    return [p if int(f.item()) else None for p, f in zip(parts, flags)]
+    """One blocking round of the animation gather (the un-pipelined form, kept for callers with a single round): every rank
+    passes its finished frame ([H, W, 4] uint8) or anything of the same shape with have_frame=False; rank 0 gets the list of the
+    round's frames in rank order (None where a rank had none).  One collective: the flag rides in the frame buffer's trailer."""
+    fg = FrameGather(frame.shape[0], frame.shape[1], rank, world, frame.device, dist)
+    fg.submit(frame if have_frame else None)
+    return fg.flush()
 
 
 def animation_frames(fps, time_from, time_to):
@@ -89,27 +140,43 @@ def frame_name(output_file, starting_frame_number, frame_number):
     return "%s%06d.ppm" % (output_file, starting_frame_number + frame_number)
 
 
-def animate(frames, rank, world, dist, render_frame, on_frame=None):
+def animate(frames, rank, world, dist, render_frame, on_frame=None, shape=None, device=None):
     """N-rank animation driver: frame k of `frames` (a list of (frame_number, time)) is rendered by rank k % world with
-    render_frame(frame_number, time) -> [H, W, 4] uint8 tensor; after every round of `world` frames ONE gather brings the
-    round's frames to rank 0, which hands them to on_frame(frame_number, time, tensor) in frame order (the reference's
-    writer thread, animator.rs:27-42).  Returns the number of frames this rank rendered.  No other collective."""
+    render_frame(frame_number, time) -> [H, W, 4] uint8 tensor; ONE gather per round of `world` frames brings the round's frames
+    to rank 0, overlapped with the next round's rendering (FrameGather), and rank 0 hands them to
+    on_frame(frame_number, time, tensor) in frame order (the reference's writer thread, animator.rs:27-42).
+    shape = (H, W) and device: needed only by a rank that renders nothing in the first round (fewer frames than ranks); every rank
+    takes the same decision about that before any collective, so nobody is left waiting in one.
+    Returns the number of frames this rank rendered.  No other collective."""
+    if not frames:
+        return 0
+    if len(frames) < world and shape is None:   # (every rank evaluates the same condition: all raise, none enters a collective)
+        raise RuntimeError("animate(): fewer frames than ranks; pass shape=(H, W) and device= so that idle ranks can take part in the gather")
     rendered = 0
-    blank = None
-    for base in range(0, len(frames), world):
-        k = base + rank
-        have = k < len(frames)
-        if have:
-            frame = render_frame(*frames[k])
-            rendered += 1
-            blank = frame
-        else:
-            if blank is None:       # this rank has rendered nothing yet: it needs the frame's shape from a peer-independent source
-                raise RuntimeError("animate(): fewer frames than ranks; give every rank at least one frame")
-            frame = blank
-        parts = gather_frames(frame, have, rank, world, dist)
-        if rank == 0 and on_frame is not None:
+    fg = None
+    first = None
+
+    def deliver(base, parts):
+        if rank == 0 and on_frame is not None and parts is not None:
             for r, part in enumerate(parts):
                 if part is not None:
                     on_frame(frames[base + r][0], frames[base + r][1], part)
+
+    prev_base = None
+    for base in range(0, len(frames), world):
+        k = base + rank
+        frame = None
+        if k < len(frames):
+            frame = render_frame(*frames[k])
+            rendered += 1
+        if fg is None:
+            if frame is not None:
+                first = (frame.shape[0], frame.shape[1], frame.device)
+            else:
+                first = (shape[0], shape[1], device if device is not None else torch.device("cpu"))
+            fg = FrameGather(first[0], first[1], rank, world, first[2], dist)
+        done = fg.submit(frame)          # starts this round's gather; completes the previous round's
+        deliver(prev_base, done)
+        prev_base = base
+    deliver(prev_base, fg.flush())
     return rendered

@@ -324,6 +324,37 @@ def test_shards_tile_the_frame(rtx):
     assert rays == st.rays_total
 
 
+def test_compact_output_holds_the_shards_blocks(rtx):
+    """RTX_FLAG_COMPACT_OUTPUT: the call's own 8-row blocks, packed, equal the same rows of the full frame; the
+    StillGather de-interleave of the three shards' compact buffers is the full frame (ids too); the host-buffer call rejects it."""
+    import torch
+    flat, cam_fn = scenes.mesh_scene(rtx)
+    W, H = 96, 72                                     # 9 blocks over 3 and over 4 shards (ragged: 3,2,2,2)
+    cam = cam_fn(W, H)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=3, refract_depth=3, shadow_samples=2, pixel_samples=2, rng_mode=1, seed=3)
+    full, ids_full, st = sc.render(cam, rtx.options(**kw))
+    stream = torch.cuda.current_stream().cuda_stream
+    for world in (3, 4):
+        final = None
+        for k in range(world):
+            g = rtx.sharding.StillGather(W, H, k, world, torch.device("cuda", 0))
+            g.target.fill_(77)
+            ids = torch.full((g.max_blocks * 8, W), -7, dtype=torch.int32, device="cuda")
+            sc.render_device(cam, rtx.options(shard_index=k, shard_count=world, flags=rtx.abi.FLAG_COMPACT_OUTPUT, **kw),
+                             g.target.data_ptr(), ids.data_ptr(), stream)
+            torch.cuda.synchronize()
+            got, got_ids = g.target.cpu().numpy(), ids.cpu().numpy()
+            mine = rtx.sharding.blocks_of_rank(H, k, world)
+            for j, b in enumerate(mine):
+                assert np.array_equal(got[j * 8:j * 8 + 8], full[b * 8:b * 8 + 8])
+                assert np.array_equal(got_ids[j * 8:j * 8 + 8], ids_full[b * 8:b * 8 + 8])
+            assert (got[len(mine) * 8:] == 77).all() and (got_ids[len(mine) * 8:] == -7).all()   # nothing written past the shard's blocks
+    with pytest.raises(Exception):
+        sc.render(cam, rtx.options(flags=rtx.abi.FLAG_COMPACT_OUTPUT, **kw))
+    sc.close()
+
+
 def test_reference_order_flag_agrees(rtx, orc):
     """RTX_FLAG_REFERENCE_ORDER walks the octree exactly as the reference's unordered DFS does;
     both orders give the same image (ties between different prims are vanishingly rare)."""

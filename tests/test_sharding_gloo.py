@@ -40,8 +40,15 @@ def _worker(rank, world, port, W, H, q):
     for b in sh.blocks_of_rank(H, rank, world):
         mine[b * 8:(b + 1) * 8] = full[b * 8:(b + 1) * 8]
     g = sh.StillGather(W, H, rank, world, torch.device("cpu"))
-    out = g.gather(mine, dist)
+    out = g.gather(dist, rgba=mine)
     ok_still = bool(torch.equal(out, full)) if rank == 0 else out is None
+    # the same with the rank's blocks written straight into the compact target (what RTX_FLAG_COMPACT_OUTPUT does on the device)
+    g2 = sh.StillGather(W, H, rank, world, torch.device("cpu"))
+    assert g2.target.shape == (g2.max_blocks * 8, W, 4)
+    for j, b in enumerate(sh.blocks_of_rank(H, rank, world)):
+        g2.target[j * 8:(j + 1) * 8] = full[b * 8:(b + 1) * 8]
+    out2 = g2.gather(dist)
+    ok_still = ok_still and (bool(torch.equal(out2, full)) if rank == 0 else out2 is None)
     # animation: 5 frames over 2 ranks, rounds of `world` frames
     total = 5
     got = {}
@@ -100,6 +107,58 @@ def _anim_worker(rank, world, port, q):
     q.put((rank, n, rendered_here, written))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _short_anim_worker(rank, world, port, q):
+    """Fewer frames than ranks: the idle rank takes part in the gather with shape=/device=; without them EVERY rank raises before
+    any collective (nobody is left waiting in one)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module("rust-raytracer_amd.sharding")
+    frames = [(0, 0.25)]
+    written = []
+    raised = False
+    try:
+        sh.animate(frames, rank, world, dist, lambda k, t: torch.full((8, 4, 4), 9, dtype=torch.uint8), None)
+    except RuntimeError:
+        raised = True
+    n = sh.animate(frames, rank, world, dist, lambda k, t: torch.full((8, 4, 4), 9, dtype=torch.uint8),
+                   lambda k, t, f: written.append((k, t, int(f[7, 3, 2]))), shape=(8, 4), device=torch.device("cpu"))
+    q.put((rank, raised, n, written))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_animation_with_fewer_frames_than_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_short_anim_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]                 # both ranks raised, neither hung
+    assert (res[0][2], res[1][2]) == (1, 0)
+    assert res[0][3] == [(0, 0.25, 9)] and res[1][3] == []
+
+
+def test_frame_gather_single_rank_pipeline(rtx):
+    """FrameGather at world 1: submit returns the PREVIOUS round's frame, flush the last one; buffers alternate."""
+    sh = rtx.sharding
+    fg = sh.FrameGather(8, 4, 0, 1, torch.device("cpu"), None)
+    assert fg.submit(torch.full((8, 4, 4), 1, dtype=torch.uint8)) is None
+    d = fg.submit(torch.full((8, 4, 4), 2, dtype=torch.uint8))
+    assert len(d) == 1 and int(d[0][0, 0, 0]) == 1
+    d = fg.submit(None)
+    assert int(d[0][3, 3, 3]) == 2
+    assert fg.flush() == [None]
+    assert fg.flush() is None
 
 
 def test_two_rank_animation_driver():

@@ -92,3 +92,22 @@ def test_cli_animation_writes_numbered_frames(rtx, tmp_path):
     sc.close()
     assert (np.abs(first - rgba[..., :3].astype(np.int64)) <= 1).all()
     assert not np.array_equal(first, _read_ppm(tmp_path / frames[2]))   # the camera has moved
+
+
+@pytest.mark.gpu
+def test_cli_sphere_job_at_config_1_against_the_oracle(rtx, orc, tmp_path):
+    """BASELINE config 1 exactly as stated (main.rs:34-49 schema): the sphere scene at 512x512, 1 spp, 1 shadow sample, depth 4,
+    written in the reference's JSON job format, through the `rtx` CLI; the PPM it writes against the oracle's frame
+    (deterministic mode: every pixel within one 8-bit step on >= 99.9 %)."""
+    cfg = dict(SAMPLE, name="sphere", size=[512, 512], fov=30.0, reflect_depth=4, refract_depth=4, shadow_samples=1,
+               gloss_samples=1, pixel_samples=1, output_file="sphere", rng_mode="center")
+    p = _run(tmp_path, cfg)
+    assert "Render done" in p.stdout
+    img = _read_ppm(tmp_path / "sphere.ppm")
+    assert img.shape == (512, 512, 3)
+    named = rtx.host.NamedScene("sphere")
+    opt = rtx.options(reflect_depth=4, refract_depth=4, shadow_samples=1, gloss_samples=1, pixel_samples=1, rng_mode=0)
+    orgba, _, _ = orc.Scene(named).render(named.camera(512, 512, 30.0), opt, threads=16)
+    d = np.abs(img - orgba[..., :3].astype(np.int64)).max(axis=-1)
+    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+    assert (d == 0).mean() >= 0.99

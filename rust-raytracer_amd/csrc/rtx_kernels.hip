@@ -558,8 +558,14 @@ DEV bool surely_hit(float nx, float ny, float nz, float fx, float fy, float fz) 
 enum { WW_CLOSEST = 0, WW_ANY = 1, WW_PRODUCT = 2 };
 template <int WW>
 DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_lds, uint32_t *s_cand, double t_lo, double t_hi, Hit *hit,
-                     V3 *prod = nullptr, bool *fallback = nullptr) {
+                     V3 *prod = nullptr, bool *fallback = nullptr, bool *tie_out = nullptr) {
     constexpr bool ANY = WW == WW_ANY, PRODUCT = WW == WW_PRODUCT;
+    // TIES: two different prims hit at a bit-identical t (a ray through the shared edge or vertex of two triangles).  ray.rs:52-60 keeps the
+    // one it VISITS first (`t < nearest_t` is strict), and its visiting order is the octree's (children popped 7 -> 0, a leaf's entries in
+    // insertion order, octree.rs:177-187), which this walk does not follow.  It only notices the tie: the ray is then answered by the
+    // all-f64 walk in the reference's order (k_closest_retry / traverse_exact<MODE_CLOSEST_REF>), like a degenerate ray.  A tie that a
+    // smaller t supersedes is forgotten.  Planes come last in the reference too (octree.rs:163-165): a finite prim wins a tie with one.
+    bool tie = false;
     V3 acc = v3(1.0, 1.0, 1.0);   // WW_PRODUCT: renderer.rs:211
     bool zero = false;            // ... has reached exactly (0,0,0)
     uint32_t *stk = s_lds + threadIdx.x;     // level stack, stride RTX_BLOCK
@@ -742,10 +748,10 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                                 }
                             } else if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
-                            } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                            } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo) {
                                 // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
-                                best_t = t;
-                                best_ref = ref;
+                                if (t < best_t) { best_t = t; best_ref = ref; tie = false; }
+                                else if (t == best_t && ref != best_ref) tie = true;   // see `tie` above
                             }
                         }
                         if (PRODUCT && !occl) mbx[((uint32_t)ref & (RTX_MAILBOX - 1u)) * RTX_BLOCK] = (uint32_t)ref;   // its copies miss too
@@ -767,9 +773,9 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                                 }
                             } else if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
-                            } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
-                                best_t = t;
-                                best_ref = ref;
+                            } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo) {
+                                if (t < best_t) { best_t = t; best_ref = ref; tie = false; }
+                                else if (t == best_t && ref != best_ref) tie = true;
                             }
                         }
                         if (PRODUCT && !occl) mbx[((uint32_t)ref & (RTX_MAILBOX - 1u)) * RTX_BLOCK] = (uint32_t)ref;
@@ -781,6 +787,8 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
                 if (zero) running = false;
             } else {
                 bf = f32_above(best_t - tsh);
+                // (last_exit is the far distance of the leaf's box SHRUNK by delta: a hit on the far face itself does not end the walk, so
+                // a prim that ties with it and is listed in the next leaf only is still met)
                 if (ANY ? best_ref != REF_NONE : (best_ref != REF_NONE && best_t - tsh <= (double)last_exit)) running = false;
             }
         }
@@ -807,6 +815,7 @@ DEV void traverse_ww(const DScene &sc, const Ray &r, bool active, uint32_t *s_ld
     }
     hit->t = best_t;
     hit->ref = best_ref;
+    if (tie_out) *tie_out = tie;
     if (PRODUCT) { *prod = acc; *fallback = fb; }
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 }
@@ -856,6 +865,12 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                       bool *overflow) {
     static_assert(WW == WW_CLOSEST || WW == WW_ANY, "the shadow product walks with traverse_bvh_dealt");
     constexpr bool ANY = WW == WW_ANY;   // the window is [t_lo, t_hi] for every candidate, nothing is culled by a best hit
+    // TIES: two different prims hit at a bit-identical t (a ray through the shared edge or vertex of two triangles).  ray.rs:52-60 keeps the
+    // one it VISITS first (`t < nearest_t` is strict), and its visiting order is the octree's (children popped 7 -> 0, a leaf's entries in
+    // insertion order, octree.rs:177-187), which this walk does not follow.  It only notices the tie: the ray is then answered by the
+    // all-f64 walk in the reference's order (k_closest_retry / traverse_exact<MODE_CLOSEST_REF>), like a degenerate ray.  A tie that a
+    // smaller t supersedes is forgotten.  Planes come last in the reference too (octree.rs:163-165): a finite prim wins a tie with one.
+    bool tie = false;
     uint32_t *stk = s_stack + threadIdx.x;   // stride RTX_BLOCK
     uint32_t *cand = s_cand + threadIdx.x;   // parked candidates, stride RTX_BLOCK: (ref << 1) | surely_in
     double best_t = ANY ? t_hi : inf();      // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
@@ -972,10 +987,10 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                             double t, be, ga;
                             if (ANY) {   // renderer.rs:212: t in [EPSILON, distance_to_light]
                                 if (tri_hit(tr, r, t_lo, t_hi, &t, &be, &ga)) best_ref = ref;
-                            } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo && t < best_t) {
+                            } else if (tri_hit(tr, r, t_lo, best_t, &t, &be, &ga) && t > t_lo) {
                                 // prim.intersects(ray, t_min, nearest_t) then `t > t_min && t < nearest_t` (ray.rs:50-55)
-                                best_t = t;
-                                best_ref = ref;
+                                if (t < best_t) { best_t = t; best_ref = ref; tie = false; }
+                                else if (t == best_t && ref != best_ref) tie = true;   // see `tie` above
                             }
                         }
                     } else {
@@ -987,9 +1002,9 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                             double t;
                             if (ANY) {
                                 if (sphere_hit(cc, radius, r, t_lo, t_hi, &t)) best_ref = ref;
-                            } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo && t < best_t) {
-                                best_t = t;
-                                best_ref = ref;
+                            } else if (sphere_hit(cc, radius, r, t_lo, best_t, &t) && t > t_lo) {
+                                if (t < best_t) { best_t = t; best_ref = ref; tie = false; }
+                                else if (t == best_t && ref != best_ref) tie = true;
                             }
                         }
                     }
@@ -1016,7 +1031,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
     }
     hit->t = best_t;
     hit->ref = best_ref;
-    *overflow = ovf;
+    *overflow = ovf || tie;   // (either way: the caller runs the all-f64 walk in the reference's order)
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 }
 
@@ -1049,15 +1064,16 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
     uint32_t *stk = s_stack + threadIdx.x;                         // stride RTX_BLOCK
     uint32_t *list = s_cand + (threadIdx.x >> 6) * RTX_BVH_LIST;   // the wave's pair list
     // per-lane result words, written by whichever lane tests a pair of this lane's ray:
-    // closest: u64 best[RTX_BLOCK] (bits of t), int ref[RTX_BLOCK]; any: int ref[RTX_BLOCK]; product: u32 n_hits[RTX_BLOCK]
+    // closest: u64 best[RTX_BLOCK] (bits of t), int ref[RTX_BLOCK], u32 tie[RTX_BLOCK]; any: int ref[RTX_BLOCK]; product: u32 n_hits[RTX_BLOCK]
     unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_aux);
     int *s_ref = reinterpret_cast<int *>(CLOSEST ? s_aux + 2 * RTX_BLOCK : s_aux);
     uint32_t *s_nh = s_aux;
+    uint32_t *s_tie = CLOSEST ? s_aux + 3 * RTX_BLOCK : s_aux;   // closest: two different prims hold the minimum (see `tie` in traverse_bvh)
 #define BVH_FENCE() asm volatile("" ::: "memory")   /* LDS traffic between lanes of ONE wave: executed in order, only the compiler must not move or cache it */
     double best_t = ANY ? t_hi : inf();      // closest: nearest_t (ray.rs:47); any-hit: distance_to_light, never lowered
     int best_ref = REF_NONE;
     WORK(uint32_t w_nodes = 0; uint32_t w_entries = 0; uint32_t w_prims = 0;)
-    if constexpr (CLOSEST) { s_best[threadIdx.x] = (unsigned long long)__double_as_longlong(inf()); s_ref[threadIdx.x] = -1; }
+    if constexpr (CLOSEST) { s_best[threadIdx.x] = (unsigned long long)__double_as_longlong(inf()); s_ref[threadIdx.x] = -1; s_tie[threadIdx.x] = 0u; }
     else if constexpr (PRODUCT) s_nh[threadIdx.x] = 0u;
     else s_ref[threadIdx.x] = REF_NONE;
     BVH_FENCE();
@@ -1209,8 +1225,9 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
         }
         if constexpr (CLOSEST) {
             // s_ref holds the winner as (sphere << 24 | index), 0xFFFFFFFF = none.  Prims that tie at exactly the same t (a ray through
-            // the shared edge of two axis-aligned triangles): the lowest index wins, whichever round or lane tests it; ray.rs:52-60
-            // keeps the first it visits, which for prims listed in one leaf is the one inserted first = the lowest index
+            // the shared edge of two triangles): the lowest index is kept, whichever round or lane tests it, and s_tie is set: ray.rs:52-60
+            // keeps the first it visits in the octree's order, so the caller hands a ray whose final minimum is tied to the all-f64
+            // walk in that order (as traverse_bvh does)
             found = found && t > t_lo;
             const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
             uint32_t *s_key = reinterpret_cast<uint32_t *>(s_ref);
@@ -1218,9 +1235,13 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
             if (found) atomicMin(&s_best[ot], tb);
             BVH_FENCE();
             const bool wins = found && s_best[ot] == tb;
-            if (wins && tb < before) s_key[ot] = 0xFFFFFFFFu;   // a new minimum: the old winner goes (every lane that ties writes the same)
+            if (wins && tb < before) { s_key[ot] = 0xFFFFFFFFu; s_tie[ot] = 0u; }   // a new minimum: the old winner goes (every lane that ties writes the same)
             BVH_FENCE();
-            if (wins) atomicMin(&s_key[ot], pw & 0x01FFFFFFu);
+            if (wins) {
+                const uint32_t mine_k = pw & 0x01FFFFFFu;
+                const uint32_t old = atomicMin(&s_key[ot], mine_k);
+                if (old != 0xFFFFFFFFu && old != mine_k) s_tie[ot] = 1u;   // (set after every reset of this round: the LDS runs a wave's operations in order)
+            }
         } else if constexpr (PRODUCT) {
             // a hit that finds its owner's list full (more than RTX_BVH_HITS / 2 hits of one feeler in one round) goes back into the
             // pair list: the next round starts with phase 2 on the full list, then the pair is tested again and fits
@@ -1368,6 +1389,7 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
     hit->t = best_t;
     hit->ref = best_ref;
     *overflow = ovf;
+    if constexpr (CLOSEST) { if (s_tie[threadIdx.x] != 0u) *overflow = true; }
     if (PRODUCT) *prod = acc;
     WORK(hit->w_nodes = w_nodes; hit->w_entries = w_entries; hit->w_prims = w_prims;)
 #ifdef RTX_COUNT_FLUSH   // (with RTX_COUNT_WORK) experiment: wave-steps and test rounds instead of lane-steps and entries
@@ -1624,7 +1646,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
     constexpr bool BVH = MODE == MODE_CLOSEST_BVH || MODE == MODE_CLOSEST_BVH_DEALT;
     __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
-    __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 3 * RTX_BLOCK : 2];   // traverse_bvh_dealt: best t (u64) and ref per lane
+    __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 4 * RTX_BLOCK : 2];   // traverse_bvh_dealt: best t (u64), ref and tie flag per lane
     if constexpr (!BVH) init_lds(s_stk);
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
@@ -1650,8 +1672,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
         Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
                       : make_ray(v3(0, 0, 0), v3(0, 0, 1));
         const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
-        traverse_ww<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit);
-        if (degen) hit.ref = REF_RETRY;
+        bool tie;
+        traverse_ww<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit, nullptr, nullptr, &tie);
+        if (degen || tie) hit.ref = REF_RETRY;
     } else if constexpr (MODE == MODE_CLOSEST_BVH) {
         size_t cap = pool.cap;
         const double *f = pool.f + slot;
@@ -2893,7 +2916,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
     constexpr bool BVH = MODE == MODE_CLOSEST_BVH || MODE == MODE_CLOSEST_BVH_DEALT;
     __shared__ uint32_t s_stk[BVH ? (RTX_BVH_STACK > RTX_MAX_LEVELS ? RTX_BVH_STACK : RTX_MAX_LEVELS) * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
-    __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 3 * RTX_BLOCK : 2];
+    __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 4 * RTX_BLOCK : 2];
     if constexpr (!BVH) init_lds(s_stk);
     int64_t gid = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
     // MODE_CLOSEST_BVH_DEALT: every lane of the wave takes part in the walk (its exact tests are dealt out over the wave's 64 lanes); in
@@ -2908,8 +2931,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_nearest(DScene sc, int64_t n, con
     V3 unused;
     if constexpr (MODE == MODE_CLOSEST) {   // what k_closest + k_closest_retry do
         const bool degen = degenerate_dir(r.dx, r.dy, r.dz);
-        traverse_ww<WW_CLOSEST>(sc, r, !degen, s_stk, s_cand, T_MIN, inf(), &hit);
-        if (degen) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
+        bool tie;
+        traverse_ww<WW_CLOSEST>(sc, r, !degen, s_stk, s_cand, T_MIN, inf(), &hit, nullptr, nullptr, &tie);
+        if (degen || tie) traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
     } else if constexpr (MODE == MODE_CLOSEST_BVH) {   // what k_closest<MODE_CLOSEST_BVH> + k_closest_retry do
         const bool degen = degenerate_dir(r.dx, r.dy, r.dz);
         bool ovf;

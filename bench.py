@@ -358,6 +358,9 @@ def derive_pmc(res):
         lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) if c.get("SQ_ACTIVE_INST_VALU") else 0.0
         out[k] = {"busy": busy, "lane_utilisation": lanes,
                   "valu_insts_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
+                  # the scalar unit is ONE per CU (shared by its four SIMDs): instructions issued per CU-cycle, peak 1
+                  "salu_insts_per_wave": c.get("SQ_INSTS_SALU", 0.0) / c["SQ_WAVES"],
+                  "salu_issue_per_cu_cycle": c.get("SQ_INSTS_SALU", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8 * 256) if c.get("GRBM_GUI_ACTIVE") else None,
                   "waves_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
                   "l2_hit_rate": 1.0 - w[k]["TCC_MISS_sum"] / w[k]["TCC_REQ_sum"] if w[k].get("TCC_REQ_sum") else None,
                   "l2_request_gbs": w[k].get("TCC_REQ_sum", 0.0) * 128 / w[k]["_seconds"] / 1e9,
@@ -525,6 +528,7 @@ def measure(args, pkg, np, torch, out, scene, named, cam, opt, rgba, final, stre
             "unit": "VALU lane-slots per cycle doing a lane's work (256 CUs x 4 SIMDs x 16 lanes)" if bound == "valu" else "GB/s",
             "valu_frac": valu_frac, "valu_busy": v["busy"], "lane_utilisation": v["lane_utilisation"],
             "valu_insts_per_wave": v["valu_insts_per_wave"], "waves_waiting_frac": v.get("waves_waiting_frac"),
+            "salu_insts_per_wave": v.get("salu_insts_per_wave"), "salu_issue_per_cu_cycle": v.get("salu_issue_per_cu_cycle"),
             "hbm_frac": hbm_frac, "l2_frac": v["l2_request_gbs"] / L2_PEAK_GBS, "hbm_gbs_alone": v["hbm_gbs_alone"],
             "l2_request_gbs": v["l2_request_gbs"], "l2_hit_rate": v.get("l2_hit_rate"),
             "traffic": v["hbm_bytes_per_launch"], "traffic_write": v.get("hbm_write_bytes_per_launch"),

@@ -68,11 +68,23 @@ DEV double clamp01(double x) { return fmin(fmax(x, 0.0), 1.0); }
 // Philox4x32-10 (Salmon et al. 2011), the build's own counter-based generator: the
 // reference's thread_rng() is OS-seeded and unreproducible (renderer.rs:69, spherelight.rs:14,
 // vec3.rs:113).  Spec in DESIGN.md §RNG; the oracle implements the same spec independently.
+// the full 32 x 32 -> 64-bit product in ONE instruction (the compiler emits v_mul_hi_u32 + v_mul_lo_u32, two quarter-rate instructions:
+// sponza shadows 168.9 -> 167.5 ms with this form; -DRTX_PHILOX_MULHILO keeps the other for A/B)
+DEV uint64_t mul_wide(uint32_t a, uint32_t b) {
+#ifdef RTX_PHILOX_MULHILO
+    return ((uint64_t)__umulhi(a, b) << 32) | (uint64_t)(a * b);
+#else
+    uint64_t p, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "v"(a), "v"(b));
+    return p;
+#endif
+}
 DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = mul_wide(0xD2511F53u, c0), p1 = mul_wide(0xCD9E8D57u, c2);
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -45,12 +45,21 @@ class StillGather:
         self.row_bytes = 8 * width * 4
         self.mine = blocks_of_rank(height, rank, world)
         self.max_blocks = (self.n_blocks + world - 1) // world
-        self.compact = torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
-        self.target = self.compact.view(self.max_blocks * 8, width, 4)
         self.idx = torch.tensor(self.mine, dtype=torch.long, device=device)
-        self.parts = ([torch.zeros_like(self.compact) for _ in range(world)]
-                      if (world > 1 and rank == 0) else None)
-        self.final = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if rank == 0 else None
+        self.recv = self.parts = self.final = self.dst = None
+        if rank == 0:
+            # rank 0 receives every rank's compact buffer into ONE array and de-interleaves it with ONE indexed copy: slot (r, j) holds
+            # block r + j * world; the slots past a rank's last block go to a spare block behind the frame
+            self.recv = torch.zeros((world, self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
+            self.parts = [self.recv[r] for r in range(world)]
+            dst = [(r + j * world) if (r + j * world) < self.n_blocks else self.n_blocks for r in range(world) for j in range(self.max_blocks)]
+            self.dst = torch.tensor(dst, dtype=torch.long, device=device)
+            self._padded = torch.zeros((self.n_blocks + 1, self.row_bytes), dtype=torch.uint8, device=device)
+            self.final = self._padded[:self.n_blocks].view(height, width, 4)
+            self.compact = self.recv[0] if world == 1 else torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
+        else:
+            self.compact = torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
+        self.target = self.compact.view(self.max_blocks * 8, width, 4)
 
     def gather(self, dist=None, rgba=None):
         """Returns the assembled frame on rank 0, None elsewhere."""
@@ -60,11 +69,7 @@ class StillGather:
             dist.gather(self.compact, self.parts, dst=0)
             if self.rank != 0:
                 return None
-        out = self.final.view(self.n_blocks, self.row_bytes)
-        for r in range(self.world):
-            n = len(range(r, self.n_blocks, self.world))
-            if n:
-                out[r::self.world] = (self.parts[r] if self.world > 1 else self.compact)[:n]
+        self._padded.index_copy_(0, self.dst, self.recv.view(self.world * self.max_blocks, self.row_bytes))
         return self.final
 
 

@@ -875,7 +875,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     if (overlap && s->d.all_opaque && s->d.wide && !(fr.flags & RTX_FLAG_NO_COOP) && opt->shadow_samples % 16u == 0u && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) && !std::getenv("RTX_GENERAL_SHADE"))
         fr.flags |= RTX_FLAG_INTERNAL_SMALL_SHADE;
     hipEvent_t sq_free[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [queue][aux stream]
-    const size_t n_aux = std::min<size_t>(2, s->lights.size());
+    size_t n_aux = std::min<size_t>(2, s->lights.size());
+    if (const char *e = std::getenv("RTX_AUX_STREAMS")) n_aux = std::max<size_t>(1, std::min<size_t>(n_aux, (size_t)std::atoi(e)));   // A/B: 1 = the lights' launches one after the other
     uint32_t step = 0;
     // Every failure after the first launch leaves through here: nothing keeps running on the library's own streams (they read
     // the shadow queues and add to `acc`, which the caller may free or render into again as soon as this call has returned).

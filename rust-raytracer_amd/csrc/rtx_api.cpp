@@ -653,6 +653,7 @@ void fill_camera(DFrame &fr, const rtx_camera &c) {
 
 struct Seg {
     uint32_t begin, end;
+    uint32_t gen;   // generation of its rays: 0 = primary, g = children of generation g - 1; a ray of generation `levels` has used up its depth
 };
 
 // The device workspace of one render call: the scene handle's own buffers (ensure_work) or a carving of the static device
@@ -892,13 +893,17 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if (n_segs == 0) {
             uint32_t cnt = std::min<uint32_t>(batch, n_samples - s_next);
             rtxk_generate(stream, fr, v.pool, 0, s_next, cnt);
-            seg_push(Seg{0, cnt});
+            seg_push(Seg{0, cnt, 0});
             s_next += cnt;
         }
         Seg &top = seg_top();
         uint32_t top_end = top.end;
         uint32_t n = std::min<uint32_t>(batch, top.end - top.begin);
-        if (fanout > 0) {
+        const uint32_t top_gen = top.gen;
+        // room for the children of this launch; the rays of the LAST generation (reflect / refract counters used up) spawn none: without
+        // this a frame whose every ray spawns a child at every level (a camera inside a mirror box) fills the pool exactly and found no room
+        // for children that cannot exist (tools/exp/fuzz_campaign.py, seeds 5110 and 5118)
+        if (fanout > 0 && top_gen < need.levels) {
             uint64_t fit = (uint64_t)(pool_cap - top_end) / fanout;
             if (fit < n) n = (uint32_t)fit;
             if (n == 0) return fail(RTX_ERR_QUEUE_OVERFLOW, "ray pool exhausted; raise rtx_options.pool_rays");
@@ -975,7 +980,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         top.end = begin;
         if (top.begin == top.end) --n_segs;
         uint32_t children = back_tail - top_end;
-        if (children) seg_push(Seg{top_end, top_end + children});
+        if (children) seg_push(Seg{top_end, top_end + children, top_gen + 1});
         peak_pool = std::max<uint64_t>(peak_pool, (uint64_t)top_end + children);
         return RTX_OK;
     };

@@ -415,6 +415,38 @@ def test_pool_exhaustion_is_an_error_and_leaves_the_handle_usable(rtx):
     assert (np.abs(good.astype(int) - again.astype(int)) <= 1).all() and (good != again).mean() < 1e-3
 
 
+@pytest.mark.parametrize("depth", [2, 3, 5])
+@pytest.mark.parametrize("glass", [False, True])
+def test_every_ray_spawns_at_every_level(rtx, orc, depth, glass):
+    """A camera inside a closed box of six mirror planes (and, `glass`, transmissive ones: two children per hit): EVERY ray hits and
+    spawns its full fan-out at EVERY level, so each generation fills its share of the automatically sized ray pool exactly.  The
+    last generation spawns nothing and must not be refused for want of room for children (found by tools/exp/fuzz_campaign.py: the
+    library returned RTX_ERR_QUEUE_OVERFLOW with the default pool).  Ray counts: the full tree."""
+    b = rtx.SceneBuilder()
+    b.point_light((0.3, 0.4, -0.2), (0.9, 0.9, 0.9))
+    m = b.cook_torrance(k_a=0.05, k_d=0.5, k_s=0.4, k_sg=0.8, k_tg=0.7 if glass else 0.0, gauss_constant=5.0, roughness=0.1, ior=1.4,
+                        diffuse=(0.8, 0.7, 0.6), transmission=(0.6, 0.7, 0.8) if glass else (0.0, 0.0, 0.0))
+    for a in range(3):
+        for sgn in (-1.0, 1.0):
+            n = [0.0, 0.0, 0.0]
+            n[a] = sgn
+            b.plane(n[0], n[1], n[2], 5.0, m)            # the planes x, y, z = -+5
+    b.sphere((2.0, 0.5, 2.5), 0.8, m)
+    b.background = (0.1, 0.2, 0.3)
+    flat = b.build()
+    cam = rtx.camera((0.5, 0.2, 0.1), (3.0, 1.0, 4.0), (0, 1, 0), 40.0, 64, 40)
+    opt = rtx.options(reflect_depth=depth, refract_depth=depth, shadow_samples=1, pixel_samples=2, rng_mode=0)
+    sc = rtx.Scene(flat)
+    rgba, ids, st = sc.render(cam, opt)                  # default pool
+    sc.close()
+    orgba, oids, ocn = orc.Scene(flat).render(cam, opt)
+    assert np.array_equal(ids, oids) and (ids >= 0).all()
+    assert st.rays_total == ocn.rays_total
+    assert (np.abs(rgba[..., :3].astype(int) - orgba[..., :3].astype(int)) <= 1).all()
+    if not glass:
+        assert st.rays_reflect == (depth - 1) * st.rays_primary     # one mirror child per ray and level
+
+
 @pytest.mark.parametrize("tries", [1, 2, 4, 8, 16, 32, 64, 48, 3])
 def test_cooperative_shadows_equal_per_lane_shadows(rtx, tries):
     """The cooperative 16-lane box-list traversal and the per-lane octree walk are two exact any-hit

@@ -839,6 +839,17 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                             !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS);
 
     if (n_samples) HIPCHECK(hipMemsetAsync(v.acc, 0, (size_t)n_samples * 3 * sizeof(double), stream));
+    if (!trace_anything && d_ids && fr.n_blocks_local) {
+        // renderer.rs:106: with a depth counter at 0 trace() returns black before it looks for a hit: no primary ray is traced, every pixel
+        // of the call's blocks is a miss (-1).  (k_shade writes the ids otherwise; found by tools/exp/fuzz_campaign2.py: they were left as they were)
+        const size_t block_ints = (size_t)8 * fr.W;
+        if ((fr.flags & RTX_FLAG_COMPACT_OUTPUT) || shard_count == 1) {
+            HIPCHECK(hipMemsetAsync(d_ids, 0xFF, (size_t)fr.n_blocks_local * block_ints * sizeof(int32_t), stream));
+        } else {
+            for (uint32_t j = 0; j < fr.n_blocks_local; ++j)
+                HIPCHECK(hipMemsetAsync(d_ids + (size_t)(opt->shard_index + j * shard_count) * block_ints, 0xFF, block_ints * sizeof(int32_t), stream));
+        }
+    }
     HIPCHECK(hipMemsetAsync(v.d_ray_slots, 0, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), stream));
     if (noalloc) {
         rtxk_init_counters(stream, v.d_counters, v.d_ray_slots);   // no pinned staging buffer in this variant: a one-thread kernel

@@ -290,9 +290,17 @@ def test_zero_depth_is_black(rtx):
     """renderer.rs:106: reflect_depth or refract_depth of 0 returns zero before any ray."""
     flat, cam_fn = scenes.sphere_scene(rtx)
     sc = rtx.Scene(flat)
-    rgba, _, st = sc.render(cam_fn(32, 32), rtx.options(reflect_depth=0, refract_depth=4), want_ids=False)
-    sc.close()
+    cam = cam_fn(32, 32)
+    _, ids_hit, _ = sc.render(cam, rtx.options(reflect_depth=2, refract_depth=2))      # (leaves real ids in the handle's buffers)
+    assert (ids_hit >= 0).any()
+    rgba, ids, st = sc.render(cam, rtx.options(reflect_depth=0, refract_depth=4))
     assert (rgba[..., :3] == 0).all() and st.rays_total == 0
+    assert (ids == -1).all()              # no primary ray is traced: every pixel is a miss, not the last frame's ids
+    # ... also for the blocks of one shard only (the others stay as they were)
+    sc.render(cam, rtx.options(reflect_depth=2, refract_depth=2))
+    _, ids1, _ = sc.render(cam, rtx.options(reflect_depth=3, refract_depth=0, shard_index=1, shard_count=3))   # (Scene.render pre-fills -2)
+    sc.close()
+    assert (ids1[8:16] == -1).all() and (ids1[:8] == -2).all() and (ids1[16:] == -2).all()
 
 
 def test_shards_tile_the_frame(rtx):

@@ -317,7 +317,8 @@ def collect_pmc(args):
     res = {}
     for tag, counters in PMC_PASSES:
         cmd = ["timeout", "-s", "KILL", "150", rocprof, "--pmc"] + counters + ["-d", os.path.join(tmp, tag), "-o", tag, "--"] + \
-              child_cmd(args, ["--steps", "1", "--warmup", "0", "--serial"])   # (the kernels of the frame that is timed alone)
+              child_cmd(args, ["--steps", "1", "--warmup", "1", "--serial"])   # (the kernels of the frame that is timed alone; the warm-up
+        # frame is a handle's probe frame, which may run another instance of the cooperative shadow kernel: rtx_scene::coop_plain_frames)
         pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if pr.returncode != 0:
             raise RuntimeError("rocprofv3 pass %s failed (%d): %s" % (tag, pr.returncode, pr.stdout[-400:]))

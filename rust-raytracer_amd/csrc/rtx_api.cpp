@@ -434,6 +434,11 @@ struct rtx_scene {
     // what the last render call launched (rtx_last_kernel_names)
     RtxTraceNames last_trace;
     const char *last_shadow[RTX_MAX_LIGHTS] = {};
+    // k_shadow_coop<false, true> (wide groups handed to the per-lane kernel) earns its keep only in scenes whose frames have hit points
+    // OUTSIDE the scene's cube, i.e. on planes; it costs 1.4 % where it finds none (sponza: a ground plane nobody sees beyond the
+    // building).  A frame that ran it and handed over next to nothing switches the handle to the plain instance for the next
+    // RTX_COOP_PROBE_EVERY - 1 frames; then one frame probes again (a camera that has moved may see the plane).
+    uint32_t coop_plain_frames = 0;
     Work w;
 };
 
@@ -742,6 +747,7 @@ PoolNeed pool_need(const rtx_scene *s, const rtx_options *opt) {
     return n;
 }
 
+#define RTX_COOP_PROBE_EVERY 16
 constexpr rtx_status RTX_INTERNAL_RETRY_OVERFLOW = -1;   // render_once -> render_impl: render the frame again with exact shadows
 
 // One frame.  `noalloc`: the allocation-free variant (rtx_render_device_noalloc): the workspace is the static device scratch, every
@@ -883,6 +889,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     // atomics).  Two shadow queues alternate: k_shade of step i waits until the shadow launches of step i - 2 have
     // read theirs.  The caller's stream joins w.aux[] before the resolve.
     const bool overlap = !(fr.flags & RTX_FLAG_SERIAL) && opt->shadow_samples > 0 && !s->lights.empty();
+    const bool coop_defer = s->d.n_planes > 0 && s->coop_plain_frames == 0;   // (see rtx_scene::coop_plain_frames)
+    bool coop_defer_ran = false;
     // the shadow feelers of this frame run in k_shadow_coop<false> beside the next step's closest-hit / shade launches: k_shade's small instance
     if (overlap && s->d.all_opaque && s->d.wide && !(fr.flags & RTX_FLAG_NO_COOP) && opt->shadow_samples % 16u == 0u && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) && !std::getenv("RTX_GENERAL_SHADE"))
         fr.flags |= RTX_FLAG_INTERNAL_SMALL_SHADE;
@@ -962,7 +970,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                     if ((st = next_event(&sp_s.a)) || (st = next_event(&sp_s.b))) return st;
                     HIPCHECK(hipEventRecord(sp_s.a, sstream));
                 }
-                s->last_shadow[li] = rtxk_shadow(sstream, s->d, fr, sq, (uint32_t)li, n, tries, v.d_counters, v.acc);
+                s->last_shadow[li] = rtxk_shadow(sstream, s->d, fr, sq, (uint32_t)li, n, tries, v.d_counters, v.acc, coop_defer);
+                coop_defer_ran = coop_defer_ran || std::strcmp(s->last_shadow[li], "k_shadow_coop<false, true>") == 0;
                 ++launches_shadow;
                 if (timing) {
                     HIPCHECK(hipEventRecord(sp_s.b, sstream));
@@ -1024,6 +1033,11 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if (stats)
             HIPCHECK(hipMemcpyAsync(h_slots, v.d_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
+        if (coop_defer_ran) {
+            if (h_back->coop_deferred <= n_samples / 4096u) s->coop_plain_frames = RTX_COOP_PROBE_EVERY - 1;
+        } else if (s->coop_plain_frames > 0) {
+            --s->coop_plain_frames;
+        }
         if (uses_retry && h_back->retry_overflow) return RTX_INTERNAL_RETRY_OVERFLOW;
         if (!stats) return RTX_OK;
         std::memset(stats, 0, sizeof(*stats));

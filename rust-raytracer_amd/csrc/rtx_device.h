@@ -212,7 +212,9 @@ struct DCounters {
     // of (pool_tail, overflow) never clears it while shadow launches of an earlier step are still running; the host reads it
     // once, after the frame's last shadow launch.
     uint32_t retry_overflow;
-    uint32_t pad_;
+    // queue groups k_shadow_coop<false, true> has handed to the per-lane kernel in this frame (wide beams: hit points outside the scene's
+    // cube); behind `ray_slots` like retry_overflow, cleared with it at the start of a frame, read once after it
+    uint32_t coop_deferred;
 };
 
 // ---- launch wrappers implemented in rtx_kernels.hip (all enqueue on `stream`) -----------
@@ -230,7 +232,8 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                 RtxTraceNames *names = nullptr);
 // returns the name of the kernel that does the launch's work ("" when nothing was launched)
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
-                 uint32_t tries, DCounters *counters, double *acc);
+                 uint32_t tries, DCounters *counters, double *acc,
+                        bool coop_defer /* k_shadow_coop<false, true> where 16 tries or a multiple share a hit point: see the kernel */);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);
 void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *direction,
                   int32_t *prim_id, double *t_out, uint32_t flags);

@@ -2057,19 +2057,25 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
 #ifndef RTX_PRODUCT_BVH_WAVES
 #define RTX_PRODUCT_BVH_WAVES 4   // the two-phase shadow product: 128 VGPRs, no spills (at 5: 84 B of scratch per lane); heptoroid 703 -> 666 ms
 #endif
-template <int MODE>
-__global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_BVH_WAVES : (MODE == MODE_PRODUCT_FAST ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES))) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
-                                                       uint32_t tries, uint32_t pow2_tries, DCounters *counters, double *acc,
-                                                       const uint32_t *group_list) {
-    // group_list != nullptr: the launch works through a list of queue groups (what k_shadow_coop<MULTI> left over: count, then the
-    // groups) instead of the whole queue; the grid is sized for the whole queue and blocks past the list's end leave at once
+template <int MODE, bool LOOP>
+DEV void shadow_kernel_body(const DScene &sc, const DFrame &fr, const DShadowQ &sq, uint32_t light, uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
+                            DCounters *counters, double *acc, const uint32_t *group_list) {
+    // group_list != nullptr: the launch works through a list of queue groups (what a cooperative kernel left over: count, then the
+    // groups) instead of the whole queue: with a full-size grid whose blocks past the list's end leave at once (k_shadow), or with a
+    // small grid whose workgroups take the list's blocks in turn (k_shadow_list: LOOP, below)
     constexpr bool BVH = MODE == MODE_ANY_BVH || MODE == MODE_PRODUCT_BVH;
     __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[(MODE == MODE_ANY || MODE == MODE_PRODUCT_FAST) ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
     __shared__ uint32_t s_hits[MODE == MODE_PRODUCT_BVH ? RTX_BVH_HITS * RTX_BLOCK : 1];
     __shared__ uint32_t s_aux[MODE == MODE_PRODUCT_BVH ? RTX_BLOCK : 1];   // traverse_bvh_dealt: the length of the hit list, per lane
     if constexpr (!BVH) init_lds(s_stk);
-    uint64_t gid = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    // LOOP: a launch that works through a list (group_list) with a SMALL grid: its workgroups take the list's blocks of RTX_BLOCK
+    // feelers in turn (the list's length is known on the device only; a full-size grid of workgroups that find nothing to do costs
+    // 0.14 ms per launch).  An instance of its own: the loop costs the per-lane walk 24 spilled VGPRs, which the launches that do
+    // the frame's work must not pay.  !LOOP: one pass, blk = blockIdx.x.
+    static_assert(!LOOP || MODE == MODE_ANY_BVH || MODE == MODE_ANY, "list launches with a small grid: the any-hit walks");
+    for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {
+    uint64_t gid = (uint64_t)blk * RTX_BLOCK + threadIdx.x;
     const uint32_t tries_shift = (uint32_t)__ffs((int)tries) - 1u;   // (no 64-bit division for the usual try counts)
     uint32_t group = pow2_tries ? (uint32_t)(gid >> tries_shift) : (uint32_t)(gid / tries);
     uint32_t k = pow2_tries ? ((uint32_t)gid & (tries - 1u)) : (uint32_t)(gid % tries);
@@ -2078,7 +2084,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
     bool valid = group < n_groups;
     if (group_list) {
         const uint32_t n_list = group_list[0];
-        if ((uint64_t)blockIdx.x * RTX_BLOCK >= (uint64_t)n_list * tries) return;   // (the whole workgroup)
+        if ((uint64_t)blk * RTX_BLOCK >= (uint64_t)n_list * tries) return;   // (the whole workgroup)
         valid = group < n_list;
         group = valid ? group_list[1u + group] : 0u;
     }
@@ -2088,7 +2094,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
     uint64_t key = 0;
     uint32_t sample = 0;
     if (valid) sample = sq.sample[(size_t)light * qc + group];
-    if (!group_list && (uint64_t)blockIdx.x * RTX_BLOCK >= (uint64_t)n_act * tries) return;   // (the whole workgroup)
+    if (!group_list && (uint64_t)blk * RTX_BLOCK >= (uint64_t)n_act * tries) return;   // (the whole workgroup)
     valid = valid && group < n_act && sample != SHADOW_GROUP_EMPTY;
     if (valid) {
         const double *f = sq.f + (size_t)light * 6 * qc + group;
@@ -2177,6 +2183,21 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVE
     } else if (valid) {
         acc_add(acc, sample, w * scale(v, inv_tries));
     }
+    if constexpr (!LOOP) return;
+    }
+}
+
+#define RTX_SHADOW_BOUNDS(MODE) __launch_bounds__(RTX_BLOCK, MODE == MODE_ANY_BVH ? RTX_BVH_WAVES : (MODE == MODE_PRODUCT_BVH ? RTX_PRODUCT_BVH_WAVES : (MODE == MODE_PRODUCT_FAST ? RTX_PRODUCT_WAVES : RTX_SHADOW_WAVES)))
+template <int MODE>
+__global__ void RTX_SHADOW_BOUNDS(MODE) k_shadow(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
+                                                 DCounters *counters, double *acc, const uint32_t *group_list) {
+    shadow_kernel_body<MODE, false>(sc, fr, sq, light, n_groups, tries, pow2_tries, counters, acc, group_list);
+}
+// the same through a list with a small grid (see LOOP above)
+template <int MODE>
+__global__ void RTX_SHADOW_BOUNDS(MODE) k_shadow_list(DScene sc, DFrame fr, DShadowQ sq, uint32_t light, uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
+                                                      DCounters *counters, double *acc, const uint32_t *group_list) {
+    shadow_kernel_body<MODE, true>(sc, fr, sq, light, n_groups, tries, pow2_tries, counters, acc, group_list);
 }
 
 // The retry list of one any-hit shadow launch (degenerate feelers, see degenerate_dir): each feeler is rebuilt exactly as k_shadow
@@ -2298,7 +2319,8 @@ DEV float grp_max(float v) {
 #ifndef RTX_COOP_WIDE
 #define RTX_COOP_WIDE 0.02f   // largest spread of a group's hit points, as a fraction of the scene's radius
 #endif
-template <bool MULTI>
+// DEFER (always with MULTI): groups with a wide beam go on the list sq.wide for the per-lane kernel launched next (see `wide` below).
+template <bool MULTI, bool DEFER>
 __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_COOP_WAVES) k_shadow_coop(DScene sc, DFrame fr, DShadowQ sq, uint32_t light,
                                                                             uint32_t n_groups, uint32_t tries, uint32_t pow2_tries,
                                                                             DCounters *counters, double *acc) {
@@ -2441,22 +2463,37 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     grp_min_max(walk ? f32_below(o0) : INF, walk ? f32_above(o0) : -INF, &o0min, &o0max);
     grp_min_max(walk ? f32_below(o1) : INF, walk ? f32_above(o1) : -INF, &o1min, &o1max);
     grp_min_max(walk ? f32_below(o2) : INF, walk ? f32_above(o2) : -INF, &o2min, &o2max);
-    // MULTI: a group whose hit points are spread out (or whose feelers point in mixed directions) makes a beam that
-    // touches much of the hierarchy: it is left to the per-lane kernel.  Group-uniform (from the reductions).
+    // A group whose origins are spread out (MULTI: its hit points; one hit point: a point OUTSIDE the scene's cube, on a plane that
+    // runs to the horizon, whose feelers enter the cube far apart: the origins above are the entry points) or whose feelers point in
+    // mixed directions makes a beam that touches much of the hierarchy: it is left to the per-lane kernel that runs next, through the
+    // list sq.wide.  (Without this a bunny on a ground plane with 16 tries spent 10.7 ms per frame in this kernel for the feelers of
+    // its floor, the per-lane kernel 0.4 ms for all of them.)  MULTI always; one hit point per group: the DEFER instance, which the
+    // host launches for scenes with planes while frames keep finding such groups (rtx_api.cpp: coop_defer), with a power of two of
+    // tries (a queue group then lies within one wave; its rows must take the same decision).  Uniform over the queue group.
+    static_assert(DEFER || !MULTI, "k_shadow_coop<MULTI> always defers");
     bool wide = false;
-    if (MULTI) {
+    constexpr bool can_defer = DEFER;
+    if constexpr (can_defer) {
         const float spread = fmaxf(fmaxf(o0max - o0min, o1max - o1min), o2max - o2min);   // NaN / -inf (no walker): not wide
         wide = !beam_ok || spread > RTX_COOP_WIDE * (float)sc.radius;
+        if (!MULTI && tries > 16u) {   // the rows of one queue group agree
+            const unsigned long long wm = __ballot(wide);
+            const unsigned long long mine = tries >= 64u ? ~0ull : (((1ull << tries) - 1ull) << (lane & ~(tries - 1u)));
+            wide = (wm & mine) != 0ull;
+        }
     }
-    if (degen && !wide) retry_append(sq, light, (uint32_t)gid, sample, counters);   // (a wide group is left to k_shadow<MODE_ANY>, which appends)
-    if constexpr (MULTI) {   // the queue groups of a wide unit go on the list of the per-lane kernel that runs next: one atomic per wave
+    if (degen && !wide) retry_append(sq, light, (uint32_t)gid, sample, counters);   // (a wide group is left to the per-lane kernel, which appends)
+    if constexpr (can_defer) {   // the queue groups of a wide unit go on the list of the per-lane kernel that runs next: one atomic per wave
         uint32_t *wl = sq.wide + (size_t)light * (1u + qc);
         const bool app = valid && wide && k == 0u;
         const unsigned long long am = __ballot(app);
         if (am != 0ull) {
             const int leader = __ffsll((long long)am) - 1;
             uint32_t base = 0u;
-            if ((int)lane == leader) base = atomicAdd(wl, (uint32_t)__popcll(am));
+            if ((int)lane == leader) {
+                base = atomicAdd(wl, (uint32_t)__popcll(am));
+                if (!MULTI) atomicAdd(&counters->coop_deferred, (uint32_t)__popcll(am));   // (read by the host after the frame: is the DEFER instance earning its keep?)
+            }
             base = (uint32_t)__shfl((int)base, leader);
             if (app) wl[1u + base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = group;
         }
@@ -3097,7 +3134,7 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                            hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));
 }
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
-                        uint32_t tries, DCounters *counters, double *acc) {
+                        uint32_t tries, DCounters *counters, double *acc, bool coop_defer) {
     if (n_groups == 0 || tries == 0) return "";
     uint32_t pow2 = (tries <= 64u && (tries & (tries - 1u)) == 0u) ? 1u : 0u;
     uint64_t lanes = (uint64_t)n_groups * tries;
@@ -3110,12 +3147,15 @@ const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr,
     const bool product_bvh = !sc.all_opaque && !exact && !(fr.flags & RTX_FLAG_REFERENCE_ORDER) && bvh && sc.prim_leaves;
     // the any-hit kernels hand degenerate feelers to k_shadow_retry, the two-phase product those it cannot answer
     const bool any_hit = (sc.all_opaque != 0 && !exact) || product_bvh;
+    // the per-lane kernel behind k_shadow_coop<false, true> works through a list that is usually short and whose length only the device
+    // knows: a small grid, looping (k_shadow<.., LOOP>)
+    const unsigned list_grid = std::min<unsigned>(grid_for(lanes), 2048u);
     if (any_hit) (void)hipMemsetAsync(sq.retry + (size_t)light * (2u + 2u * (size_t)sq.retry_cap), 0, sizeof(uint32_t), (hipStream_t)stream);
     // the name of the kernel the chain below picks for the launch's work (the same conditions, in the same order)
     static_assert(MODE_ANY == 2 && MODE_PRODUCT == 3 && MODE_PRODUCT_FAST == 4 && MODE_ANY_BVH == 6 && MODE_PRODUCT_BVH == 7, "the kernel names below");
     const char *name = exact ? "k_shadow<3>"
-                       : (coop && tries % 16u == 0u) ? "k_shadow_coop<false>"
-                       : (coop && (tries == 4u || tries == 8u)) ? "k_shadow_coop<true>"
+                       : (coop && tries % 16u == 0u) ? ((coop_defer && pow2 != 0u) ? "k_shadow_coop<false, true>" : "k_shadow_coop<false, false>")
+                       : (coop && (tries == 4u || tries == 8u)) ? "k_shadow_coop<true, true>"
                        : (sc.all_opaque && bvh) ? "k_shadow<6>"
                        : sc.all_opaque ? "k_shadow<2>"
                        : (fr.flags & RTX_FLAG_REFERENCE_ORDER) ? "k_shadow<3>"
@@ -3124,13 +3164,28 @@ const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr,
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc, nullptr);
     else if (coop && tries % 16u == 0u) {        // the 16 lanes of a group = feelers of one hit point
-        hipLaunchKernelGGL(k_shadow_coop<false>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc);
+        // coop_defer (scenes with planes whose frames keep finding them): hit points outside the scene's cube, whose 16 feelers enter it
+        // far apart, go to the per-lane kernel through the list sq.wide (see `wide` in the kernel)
+        const bool defer = coop_defer && pow2 != 0u;
+        if (defer) {
+            (void)hipMemsetAsync(sq.wide + (size_t)light * (1u + (size_t)sq.cap), 0, sizeof(uint32_t), (hipStream_t)stream);
+            hipLaunchKernelGGL((k_shadow_coop<false, true>), dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                               n_groups, tries, pow2, counters, acc);
+        } else {
+            hipLaunchKernelGGL((k_shadow_coop<false, false>), dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                               n_groups, tries, pow2, counters, acc);
+        }
+        if (defer && bvh)
+            hipLaunchKernelGGL(k_shadow_list<MODE_ANY_BVH>, dim3(list_grid), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                               n_groups, tries, pow2, counters, acc, sq.wide + (size_t)light * (1u + (size_t)sq.cap));
+        else if (defer)
+            hipLaunchKernelGGL(k_shadow_list<MODE_ANY>, dim3(list_grid), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+                               n_groups, tries, pow2, counters, acc, sq.wide + (size_t)light * (1u + (size_t)sq.cap));
     } else if (coop && (tries == 4u || tries == 8u)) {   // measured: with 1 try per hit point (16 origins per group) the per-lane walk wins
         // groups of 16 / tries neighbouring hit points: the cooperative kernel takes the compact ones and lists the others
         // (sq.wide) for the per-lane kernel, which works through that list in full waves
         (void)hipMemsetAsync(sq.wide + (size_t)light * (1u + (size_t)sq.cap), 0, sizeof(uint32_t), (hipStream_t)stream);
-        hipLaunchKernelGGL(k_shadow_coop<true>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
+        hipLaunchKernelGGL((k_shadow_coop<true, true>), dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
                            n_groups, tries, pow2, counters, acc);
         if (bvh)
             hipLaunchKernelGGL(k_shadow<MODE_ANY_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,

@@ -1422,12 +1422,20 @@ DEV void traverse(const DScene &sc, const Ray &r, uint32_t *s_lds, double t_lo, 
 struct C4 {
     double r, g, b, a;
 };
+// p / 255.0 (colorrgba.rs:116-124) for p = 0 .. 255 without the division sequence: the product with RN(1 / 255) and one residual
+// correction, bit-identical to the IEEE quotient for every one of the 256 arguments (checked exhaustively: tests/test_oracle_known_answers.py)
+DEV double u8_over_255(uint8_t p) {
+    const double c = 0x1.010101010101p-8;   // RN(1 / 255)
+    const double pd = (double)p;
+    const double q = pd * c;
+    return fma(fma(-255.0, q, pd), c, q);
+}
 DEV C4 px_f64(const uint8_t *atlas, const DImage &im, long long x, long long y) {
     // the reference panics out of range (surface.rs:102-109; only 1-pixel-wide/high images): clamp
     if (x >= im.w) x = im.w - 1;
     if (y >= im.h) y = im.h - 1;
     uchar4 p = *reinterpret_cast<const uchar4 *>(atlas + im.offset + (y * (long long)im.w + x) * 4);
-    return C4{p.x / 255.0, p.y / 255.0, p.z / 255.0, p.w / 255.0};                      // colorrgba.rs:116-124
+    return C4{u8_over_255(p.x), u8_over_255(p.y), u8_over_255(p.z), u8_over_255(p.w)};  // colorrgba.rs:116-124
 }
 DEV C4 cmul(C4 c, double s) { return C4{c.r * s, c.g * s, c.b * s, c.a}; }               // colorrgba.rs:178-189
 DEV C4 cadd(C4 a, C4 b) { return C4{a.r + b.r, a.g + b.g, a.b + b.b, a.a + b.a}; }       // colorrgba.rs:138-148
@@ -1491,40 +1499,67 @@ DEV V3 cubemap_color(const DScene &sc, V3 dir) {                                
 }
 
 // ------------------------------------------------------------------------------ materials
+// What Material::sample needs of a hit that does not depend on the light: computed once per hit, not once per light (the texture
+// lookup alone is a chain of three dependent fetches and a bilinear blend; same operations, same order, same bits).
+struct MatHit {
+    int kind;
+    V3 texc;                 // diffuse_texture colour at (u, v), or white
+    V3 ambient;              // ambient.scale(k_a)
+    V3 diffuse_kd;           // diffuse.scale(k_d)
+    V3 specular_c;
+    double k_s, shine, gauss_constant;
+    double f0;               // cooktorrancematerial.rs:43
+    double sqrt_shine;       // roughness.sqrt(), cooktorrancematerial.rs:48
+};
+DEV MatHit material_prepare(const DScene &sc, const rtx_material &m, double u, double v) {
+    MatHit h;
+    h.kind = m.kind;
+    h.diffuse_kd = v3(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
+    h.texc = v3(1.0, 1.0, 1.0);
+    h.ambient = h.specular_c = v3(0.0, 0.0, 0.0);
+    h.k_s = h.shine = h.gauss_constant = h.f0 = h.sqrt_shine = 0.0;
+    if (m.kind == RTX_MAT_FLAT) return h;                                                // flatmaterial.rs:11-13
+    h.specular_c = v3(m.specular[0], m.specular[1], m.specular[2]);
+    h.texc = m.texture >= 0 ? texture_color(sc, m.texture, u, v) : v3(1.0 / 1.0, 1.0 / 1.0, 1.0 / 1.0);
+    h.ambient = scale(v3(m.ambient[0], m.ambient[1], m.ambient[2]), m.k_a);
+    h.diffuse_kd = scale(h.diffuse_kd, m.k_d);
+    h.k_s = m.k_s; h.shine = m.shine; h.gauss_constant = m.gauss_constant;
+    if (m.kind == RTX_MAT_COOK_TORRANCE) {
+        double n1 = 1.0, n2 = m.ior;
+        double f0r = (n1 - n2) / (n1 + n2);
+        h.f0 = f0r * f0r;
+        h.sqrt_shine = sqrt(m.shine);
+    }
+    return h;
+}
 // PHONG = false: the instance for scenes without a Phong material (k_shade<false>), without the generic pow() of phongmaterial.rs:33.
 template <bool PHONG = true>
-DEV V3 material_sample(const DScene &sc, const rtx_material &m, V3 n, V3 i, V3 l, double u, double v) {
-    V3 diffuse_c = v3(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
-    if (m.kind == RTX_MAT_FLAT) return diffuse_c;                                        // flatmaterial.rs:11-13
-    V3 ambient_c = v3(m.ambient[0], m.ambient[1], m.ambient[2]);
-    V3 specular_c = v3(m.specular[0], m.specular[1], m.specular[2]);
-    V3 texc = m.texture >= 0 ? texture_color(sc, m.texture, u, v) : v3(1.0 / 1.0, 1.0 / 1.0, 1.0 / 1.0);
+DEV V3 material_sample(const MatHit &m, V3 n, V3 i, V3 l) {
+    if (m.kind == RTX_MAT_FLAT) return m.diffuse_kd;                                     // flatmaterial.rs:11-13
     if (m.kind == RTX_MAT_COOK_TORRANCE) {                                               // cooktorrancematerial.rs:26-58
-        V3 ambient = scale(ambient_c, m.k_a);
-        V3 diffuse = scale(scale(diffuse_c, m.k_d), dot(n, l)) * texc;
+        V3 diffuse = scale(m.diffuse_kd, dot(n, l)) * m.texc;
         V3 h = unit(l + i);
         double n_dot_h = dot(n, h);
         double n_dot_l = dot(n, l);
         double v_dot_h = dot(i, h);
         double n_dot_v = dot(n, i);
-        double n1 = 1.0, n2 = m.ior;
-        double f0r = (n1 - n2) / (n1 + n2);
-        double f0 = f0r * f0r;
-        double f = pow(1.0 - v_dot_h, 5.0) * (1.0 - f0) + f0;
+        // powf(5.0) by multiplication: four roundings, within 2 ulp of the exact power (libm's pow, which the reference calls, promises
+        // < 1 ulp and is platform-dependent in its last bit anyway; the parity bar for shading is 1e-12 relative)
+        const double c1 = 1.0 - v_dot_h, c2 = c1 * c1;
+        double f = (c2 * c2 * c1) * (1.0 - m.f0) + m.f0;
         double alpha = acos(n_dot_h);
-        double d = m.gauss_constant * exp(-alpha / sqrt(m.shine));
+        double d = m.gauss_constant * exp(-alpha / m.sqrt_shine);
         double g1 = (2.0 * n_dot_h * n_dot_v) / v_dot_h;
         double g2 = (2.0 * n_dot_h * n_dot_l) / v_dot_h;
         double g = fmin(g1, g2);
         double brdf = f * d * g / (n_dot_v * n_dot_l * PI);
-        return scale(specular_c, m.k_s * brdf) + diffuse + ambient;
+        return scale(m.specular_c, m.k_s * brdf) + diffuse + m.ambient;
     }
-    if constexpr (!PHONG) return diffuse_c;   // (not reached: the host launches this instance for scenes without Phong materials only)
+    if constexpr (!PHONG) return m.diffuse_kd;   // (not reached: the host launches this instance for scenes without Phong materials only)
     V3 h = unit(l + i);                                                                  // phongmaterial.rs:24-36
-    V3 ambient = scale(ambient_c, m.k_a);
-    V3 diffuse = scale(scale(diffuse_c, m.k_d), dot(n, l)) * texc;
-    V3 specular = scale(scale(specular_c, m.k_s), pow(dot(n, h), m.shine));
-    return ambient + diffuse + specular;
+    V3 diffuse = scale(m.diffuse_kd, dot(n, l)) * m.texc;
+    V3 specular = scale(scale(m.specular_c, m.k_s), pow(dot(n, h), m.shine));
+    return m.ambient + diffuse + specular;
 }
 DEV double fresnel_reflect(double ior, V3 i, V3 n, bool inside) {                       // renderer.rs:226-247
     double n1 = inside ? ior : 1.0, n2 = inside ? 1.0 : ior;
@@ -1957,6 +1992,8 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
         iv = unit(-d);
     }
 
+    MatHit mh{};
+    if (is_hit && sc.n_lights > 0) mh = material_prepare(sc, m, hu, hv);
     for (int li = 0; li < sc.n_lights; ++li) {
         bool emit = false;
         V3 w = v3(0, 0, 0);
@@ -1966,7 +2003,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
 #ifdef RTX_ABL_SHADE_NOBRDF
             V3 smp = v3(dot(n, l), hu, hv);
 #else
-            V3 smp = material_sample<GENERAL>(sc, m, n, iv, l, hu, hv);
+            V3 smp = material_sample<GENERAL>(mh, n, iv, l);
 #endif
             w = thr * (v3(lt.color[0], lt.color[1], lt.color[2]) * smp);
             if (fr.shadow_samples == 0u) acc_add(acc, sample, w);                        // renderer.rs:191: shadow = one
@@ -3063,7 +3100,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_shade_probe(DScene sc, int which,
         r = reflect(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]));
         break;
     case RTX_PROBE_MATERIAL:   // material row, n, i, l, u, v             (Material::sample of the row's kind)
-        r = material_sample(sc, sc.materials[(int)a[0]], v3(a[1], a[2], a[3]), v3(a[4], a[5], a[6]), v3(a[7], a[8], a[9]), a[10], a[11]);
+        r = material_sample(material_prepare(sc, sc.materials[(int)a[0]], a[10], a[11]), v3(a[1], a[2], a[3]), v3(a[4], a[5], a[6]), v3(a[7], a[8], a[9]));
         break;
     case RTX_PROBE_TEXTURE:    // texture row, u, v                       (Texture::color of the row's kind)
         r = texture_color(sc, (int)a[0], a[1], a[2]);

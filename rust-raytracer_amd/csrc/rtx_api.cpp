@@ -614,7 +614,7 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         if (w.hit_t) { hipFree(w.hit_t); hipFree(w.hit_ref); hipFree(w.group_base); w.hit_t = nullptr; w.hit_ref = nullptr; w.group_base = nullptr; w.hit_cap = 0; }
         rtx_status st;
         if ((st = dev_alloc(&w.hit_t, batch)) || (st = dev_alloc(&w.hit_ref, batch))) return st;
-        if ((st = dev_alloc(&w.group_base, 2 * ((size_t)batch / RTX_BLOCK + 2)))) return st;
+        if ((st = dev_alloc(&w.group_base, 4 * ((size_t)batch / RTX_BLOCK + 2)))) return st;
         w.hit_cap = batch;
     }
     if (!w.d_counters) {
@@ -692,7 +692,7 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t fixed = up(sizeof(DCounters)) + up(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)) +
                          up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 21 * 256 /* alignment of the arrays below */;
-    // per ray of a batch: hit record 12 (+ 8 per workgroup for the queue slots), pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
+    // per ray of a batch: hit record 12 (+ 16 per workgroup for the queue and pool slots), pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
     // one entry per light in the list of groups left to the per-lane shadow kernel 4
     const size_t pool_per = std::max<uint64_t>(need.per_batch, 1 + (uint64_t)need.fanout);
     const size_t per = 12 + 1 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4;
@@ -711,7 +711,7 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     v.acc = (double *)take((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double));
     v.hit_t = (double *)take(batch * sizeof(double));
     v.hit_ref = (int32_t *)take(batch * sizeof(int32_t));
-    v.group_base = (uint32_t *)take(2 * (batch / RTX_BLOCK + 2) * sizeof(uint32_t));
+    v.group_base = (uint32_t *)take(4 * (batch / RTX_BLOCK + 2) * sizeof(uint32_t));
     v.pool.f = (double *)take(pool_cap * 9 * sizeof(double));
     v.pool.key = (uint64_t *)take(pool_cap * sizeof(uint64_t));
     v.pool.sample = (uint32_t *)take(pool_cap * sizeof(uint32_t));
@@ -942,7 +942,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         }
         const DShadowQ &sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
-                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, &s->last_trace);
+                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));
@@ -1247,8 +1247,26 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         if (m.glossiness > 2.220446049250313e-16) s->any_glossy = true;
     }
 
+    // what a ray that hits a prim spawns (DScene.ref_class): one byte per prim from its material, the three kinds one after the other
+    std::vector<uint8_t> ref_class(n_tri + n_sph + planes.size() + 1, 0);
+    {
+        std::vector<uint8_t> mat_class(materials.size(), 0);
+        for (size_t i = 0; i < materials.size(); ++i) {
+            const rtx_material &m = materials[i];
+            if (m.kind == RTX_MAT_FLAT) continue;                                        // flatmaterial.rs:15-21
+            mat_class[i] = (uint8_t)((m.k_sg > 0.0 ? RTX_CLS_REFLECT : 0u) | (m.k_tg > 0.0 ? RTX_CLS_REFRACT : 0u) |
+                                     (m.glossiness > 2.220446049250313e-16 ? RTX_CLS_GLOSSY : 0u));
+        }
+        for (size_t i = 0; i < n_tri; ++i) ref_class[i] = mat_class[(size_t)d->tri_material[i]];
+        for (size_t i = 0; i < n_sph; ++i) ref_class[n_tri + i] = mat_class[(size_t)d->sphere_material[i]];
+        for (size_t j = 0; j < planes.size(); ++j) ref_class[n_tri + n_sph + j] = mat_class[(size_t)planes[j].material];
+    }
+
     // everything that is ready goes to the device now, on the uploader's thread, while this thread builds the rest
     DScene &ds = s->d;
+    up.submit(ref_class, &ds.ref_class);
+    ds.cls_spheres = (int32_t)n_tri;
+    ds.cls_planes = (int32_t)(n_tri + n_sph);
     up.submit(tris.get(), n_tri, &ds.tris);
     up.submit(shade.get(), n_tri, &ds.tri_shade);
     up.submit(spheres.get(), n_sph, &ds.spheres);

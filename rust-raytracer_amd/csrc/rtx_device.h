@@ -104,6 +104,9 @@ struct DImage {
     int64_t offset; // byte offset of the RGBA8 pixels in the atlas
 };
 
+#define RTX_CLS_REFLECT 1u   // is_reflective(): k_sg > 0 (not for FlatMaterial)
+#define RTX_CLS_REFRACT 2u   // is_refractive(): k_tg > 0
+#define RTX_CLS_GLOSSY 4u    // is_glossy(): glossiness > f64::EPSILON
 #define RTX_SHADE_GLOSSY 1u   // some material has glossiness > f64::EPSILON (renderer.rs:155: Ray::perturb)
 #define RTX_SHADE_PHONG 2u    // some material is a PhongMaterial (phongmaterial.rs:33: powf(shininess))
 struct DScene {
@@ -123,6 +126,10 @@ struct DScene {
     const DTriShade *tri_shade;
     const DSphere *spheres;
     const DPlane *planes;
+    // what a ray that hits the prim spawns, from the prim's material (RTX_CLS_*): triangles [0, n), spheres from cls_spheres, planes from
+    // cls_planes; read by the pass that counts a step's children and by k_shade (rtx_kernels.hip: spawn_counts)
+    const uint8_t *ref_class;
+    int32_t cls_spheres, cls_planes;
     const rtx_material *materials;
     const rtx_texture *textures;
     const DImage *images;
@@ -228,7 +235,8 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */,
                 void *record_after_closest /* hipEvent_t or NULL: recorded between the closest-hit launches and the shading launches (timing) */,
-                uint32_t *group_base /* [2 * ceil(count / RTX_BLOCK)]: workgroup counts, then their exclusive scan */,
+                uint32_t *group_base /* [4 * ceil(count / RTX_BLOCK)]: rays that hit something per workgroup, their exclusive scan; children per workgroup, their scan */,
+                uint32_t child_begin /* the pool's tail before the step: where its children go */,
                 RtxTraceNames *names = nullptr);
 // returns the name of the kernel that does the launch's work ("" when nothing was launched)
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,

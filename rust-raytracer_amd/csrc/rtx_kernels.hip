@@ -1614,6 +1614,31 @@ DEV void acc_add(double *acc, uint32_t sample, V3 c) {
     unsafeAtomicAdd(p + 2, c.z);
 }
 
+// The same for a whole wave (EVERY lane of the wave must call it, `has` = this lane has something to add): lanes next to each other
+// that add to the same sample are summed first (a segmented suffix sum over the runs of equal samples, 6 shuffle steps, skipped when
+// no run is longer than one lane) and the run's first lane adds the total.  Children sit in the pool in RAY order, so deep in a
+// refractive object all descendants of one primary sample are neighbours: 64 lanes x 3 atomics on ONE address, which the memory side
+// executes one after the other (heptoroid: 229 of the shadow product's 472 ms per frame, 22 of k_shade's 63).
+// The order of the additions differs from lane-by-lane atomics in the last bit, as the order of atomics itself does.
+DEV void acc_add_runs(double *acc, bool has, uint32_t sample, V3 c) {
+    const uint32_t lane = lane_id();
+    const uint32_t key = has ? sample : 0xFFFFFFFFu;   // (no sample has this index: a call renders fewer than 2^32 samples)
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = lane == 0u || prev != key;
+    if (__ballot(has && !head) != 0ull) {
+        const unsigned long long heads = __ballot(head);
+        const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));   // runs numbered from lane 0 on
+        if (!has) c = v3(0.0, 0.0, 0.0);
+#pragma unroll
+        for (uint32_t off = 1u; off < 64u; off <<= 1) {
+            const uint32_t run2 = (uint32_t)__shfl_down((int)run, off);
+            const double x = __shfl_down(c.x, off), y = __shfl_down(c.y, off), z = __shfl_down(c.z, off);
+            if (lane + off < 64u && run2 == run) { c.x += x; c.y += y; c.z += z; }
+        }
+    }
+    if (has && head) acc_add(acc, sample, c);
+}
+
 // sample index -> pixel: samples are laid out so that one wave64 = one 8x8 pixel tile of one
 // sub-sample (coherent primary rays): s = ((tile * spp + sub) * 64 + lane)
 DEV bool decode_sample(const DFrame &fr, uint32_t s, uint32_t *px, uint32_t *row, uint32_t *sub) {
@@ -1754,12 +1779,56 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
     }
 }
 
+// ---- the slots of a step's CHILDREN in the ray pool, without atomics.  Which children a ray spawns (renderer.rs:122-135) follows from the
+// material of the prim it hit (DScene.ref_class: RTX_CLS_* per prim, built with the scene) and from its depth counters, both known as soon
+// as the closest hit is: the pass that sees every ray's final hit (k_closest_retry, else k_group_count) sums them per workgroup next to
+// the number of rays that hit something, k_group_base scans both, and k_shade puts a ray's children at the step's first free slot + its
+// workgroup's base + the ray's rank.  (One returning atomic per workgroup on the pool's tail cost k_shade more than everything else it
+// does: 32 ns per workgroup of 256 rays, serialised at one address: sponza 20.6 -> ... ms)  Children are in RAY
+// ORDER, so the pool's contents no longer depend on the order in which workgroups happen to run.
+DEV uint32_t ref_class_of(const DScene &sc, int ref) {
+    if (ref >= 0 && !(ref & REF_PLANE)) return sc.ref_class[ref];
+    if (ref >= 0) return sc.ref_class[sc.cls_planes + (ref & ~REF_PLANE)];
+    return sc.ref_class[sc.cls_spheres + ~ref];
+}
+// the children of a ray that hit a prim of class `cls`: mirror / gloss rays (renderer.rs:126-129, 155-164), then one transmitted ray (:131-134);
+// a child whose depth counter reaches 0 returns zero at renderer.rs:106 and is not a ray
+DEV uint32_t spawn_counts(uint32_t cls, uint32_t flags, uint32_t gloss_samples, uint32_t *n_reflect, bool *transmit) {
+    const uint32_t reflect_depth = (flags >> RAYF_REFLECT_SHIFT) & RAYF_DEPTH_MASK;
+    const uint32_t refract_depth = (flags >> RAYF_REFRACT_SHIFT) & RAYF_DEPTH_MASK;
+    const bool spawn_reflect = (cls & RTX_CLS_REFLECT) && reflect_depth > 1u && refract_depth > 0u;
+    *transmit = (cls & RTX_CLS_REFRACT) && refract_depth > 1u && reflect_depth > 0u;
+    *n_reflect = spawn_reflect ? ((cls & RTX_CLS_GLOSSY) ? gloss_samples : 1u) : 0u;
+    return *n_reflect + (*transmit ? 1u : 0u);
+}
+// the two per-workgroup sums (every thread of the workgroup calls it): rays that hit something, children they will spawn
+DEV void block_counts(const DScene &sc, const DPool &pool, uint32_t begin, uint32_t count, uint32_t gloss_samples, int32_t ref,
+                      uint32_t *block_count, uint32_t *child_count, uint32_t *s_w /* 8 words */) {
+    const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const bool hit = gid < count && ref != REF_NONE;   // (k_closest writes REF_NONE for dead rays)
+    uint32_t nc = 0u;
+    if (hit) {
+        uint32_t n_reflect;
+        bool transmit;
+        nc = spawn_counts(ref_class_of(sc, ref), pool.flags[begin + gid], gloss_samples, &n_reflect, &transmit);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nc += (uint32_t)__shfl_xor((int)nc, off);
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0u) { s_w[wid] = (uint32_t)__popcll(m); s_w[4u + wid] = nc; }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        if (block_count) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        child_count[blockIdx.x] = s_w[4] + s_w[5] + s_w[6] + s_w[7];
+    }
+}
+
 // The all-f64 walk in the reference's visitation order for the rays k_closest<MODE_CLOSEST> has marked REF_RETRY (degenerate_dir).
 __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool pool, uint32_t begin, uint32_t count, double *hit_t,
-                                                             int32_t *hit_ref, uint32_t *block_count) {
+                                                             int32_t *hit_ref, uint32_t gloss_samples, uint32_t *block_count, uint32_t *child_count) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
-    __shared__ uint32_t s_w[RTX_BLOCK / 64];
-    const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    __shared__ uint32_t s_w[8];
+    const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     int32_t ref = gid < count ? hit_ref[gid] : REF_NONE;
     const bool mine = ref == REF_RETRY;
     if (__syncthreads_or(mine ? 1 : 0)) {   // hardly any block
@@ -1776,13 +1845,9 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool po
             ref = hit.ref;
         }
     }
-    // this pass sees every ray's final hit: the workgroup's number of rays that hit something, for the compact shadow queue (as
-    // k_group_count, which runs where this kernel does not)
-    if (!block_count) return;
-    const unsigned long long m = __ballot(ref != REF_NONE);
-    if (lane == 0u) s_w[wid] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0u) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    // this pass sees every ray's final hit: the workgroup's number of rays that hit something, for the compact shadow queue, and of
+    // the children they spawn, for their slots in the pool (as k_group_count, which runs where this kernel does not)
+    block_counts(sc, pool, begin, count, gloss_samples, ref, block_count, child_count, s_w);
 }
 
 // A degenerate shadow feeler (degenerate_dir) is left out of the any-hit kernels' sums and appended to the launch's retry list:
@@ -1800,71 +1865,67 @@ DEV void retry_append(const DShadowQ &sq, uint32_t light, uint32_t feeler, uint3
     }
 }
 
-// Block-wide allocation of `c` consecutive slots per lane from a global counter: one atomic per
-// workgroup (a per-wave atomic on one address serialises at the memory side).  Every thread of
-// the block must call it.
-DEV uint32_t block_alloc(uint32_t c, uint32_t *counter, uint32_t *s_tmp /* >= 6 words of LDS */) {
-    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6;
-    uint32_t x = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = (uint32_t)__shfl_up((int)x, off);
-        if ((int)lane >= off) x += y;
-    }
-    if (lane == 63u) s_tmp[wid] = x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
-        s_tmp[4] = tot ? atomicAdd(counter, tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_tmp[4];
-    for (uint32_t wv = 0; wv < wid; ++wv) base += s_tmp[wv];
-    return base + x - c;
-}
-
 // The slots of the compact shadow queue, in RAY order (groups appended in the order workgroups happen to finish would scatter
 // neighbouring screen tiles over the queue: measured, sibenik shadows 6.7 -> 7.2 ms): the number of rays of each workgroup that hit
 // something (k_closest_retry, or this kernel where that one does not run), the exclusive scan of these counts and their total
-// (k_group_base); k_shade adds the ray's rank within its workgroup.
+// (k_group_base); k_shade adds the ray's rank within its workgroup.  The children's slots in the pool: the same with the numbers of children.
 static_assert(RTX_BLOCK == 256, "the workgroup counts are summed over four waves");
-__global__ void __launch_bounds__(RTX_BLOCK) k_group_count(const int32_t *hit_ref, uint32_t count, uint32_t *block_count) {
-    __shared__ uint32_t s_w[RTX_BLOCK / 64];
-    const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(gid < count && hit_ref[gid] != REF_NONE);
-    if (lane == 0u) s_w[wid] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0u) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+__global__ void __launch_bounds__(RTX_BLOCK) k_group_count(DScene sc, DPool pool, uint32_t begin, uint32_t count, const int32_t *hit_ref,
+                                                           uint32_t gloss_samples, uint32_t *block_count, uint32_t *child_count) {
+    __shared__ uint32_t s_w[8];
+    const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    block_counts(sc, pool, begin, count, gloss_samples, gid < count ? hit_ref[gid] : REF_NONE, block_count, child_count, s_w);
 }
 // One workgroup per 256 counts, every load coalesced: a workgroup first sums the counts before its segment, then scans its own.
 // (One workgroup whose threads each walked 32 consecutive counts touched a cache line per lane and load: 17 us on one CU.  Workgroups
 // of 1024 threads waited 0.35 ms per launch for a CU with 16 free wave slots while shadow launches filled the chip.)
-__global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_count, uint32_t n_blocks, uint32_t *block_base, uint32_t *total_out) {
-    __shared__ uint32_t s_pre[RTX_BLOCK / 64], s_wave[RTX_BLOCK / 64];
+// Two scans at once: hits (block_count -> block_base, total -> *total_out; skipped when block_count is null: a frame without shadow
+// feelers) and children (child_count -> child_base; the last workgroup moves the pool's tail from child_begin, where the host has put it
+// for this step, past the step's children, or raises the overflow flag if they do not fit: k_shade then writes none of those).
+__global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_count, const uint32_t *child_count, uint32_t n_blocks, uint32_t *block_base,
+                                                          uint32_t *child_base, uint32_t *total_out, uint32_t child_begin, uint32_t pool_cap,
+                                                          DCounters *counters) {
+    __shared__ uint32_t s_pre[2][RTX_BLOCK / 64], s_wave[2][RTX_BLOCK / 64];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t seg0 = blockIdx.x * RTX_BLOCK, i = seg0 + threadIdx.x;
-    uint32_t pre = 0u;
-    for (uint32_t j = threadIdx.x; j < seg0; j += RTX_BLOCK) pre += block_count[j];
-    const uint32_t c = i < n_blocks ? block_count[i] : 0u;
-    uint32_t x = c;   // inclusive scan over the wave
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)x, off);
-        if ((int)lane >= off) x += y;
+    uint32_t pre[2] = {0u, 0u}, c[2], x[2];
+    for (uint32_t j = threadIdx.x; j < seg0; j += RTX_BLOCK) {
+        if (block_count) pre[0] += block_count[j];
+        pre[1] += child_count[j];
     }
+    c[0] = (block_count && i < n_blocks) ? block_count[i] : 0u;
+    c[1] = i < n_blocks ? child_count[i] : 0u;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pre += (uint32_t)__shfl_xor((int)pre, off);
-    if (lane == 63u) s_wave[wid] = x;
-    if (lane == 0u) s_pre[wid] = pre;
+    for (int a = 0; a < 2; ++a) {
+        x[a] = c[a];   // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x[a], off);
+            if ((int)lane >= off) x[a] += y;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pre[a] += (uint32_t)__shfl_xor((int)pre[a], off);
+        if (lane == 63u) s_wave[a][wid] = x[a];
+        if (lane == 0u) s_pre[a][wid] = pre[a];
+    }
     __syncthreads();
-    uint32_t before = 0u, total = 0u;
+    uint32_t before[2] = {0u, 0u}, total[2] = {0u, 0u};
 #pragma unroll
-    for (uint32_t wv = 0; wv < RTX_BLOCK / 64; ++wv) {
-        before += s_pre[wv] + (wv < wid ? s_wave[wv] : 0u);
-        total += s_pre[wv] + s_wave[wv];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (uint32_t wv = 0; wv < RTX_BLOCK / 64; ++wv) {
+            before[a] += s_pre[a][wv] + (wv < wid ? s_wave[a][wv] : 0u);
+            total[a] += s_pre[a][wv] + s_wave[a][wv];
+        }
+    if (i < n_blocks) {
+        if (block_count) block_base[i] = before[0] + x[0] - c[0];
+        child_base[i] = before[1] + x[1] - c[1];
     }
-    if (i < n_blocks) block_base[i] = before + x - c;
-    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) *total_out = total;
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) {
+        if (block_count) *total_out = total[0];
+        if ((uint64_t)child_begin + total[1] > (uint64_t)pool_cap) counters->overflow = 1u;
+        else counters->pool_tail = child_begin + total[1];
+    }
 }
 
 // K3 (+K5) shade_and_spawn: the body of Renderer::trace after the closest-hit search
@@ -1888,7 +1949,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_
 template <bool GENERAL>
 __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHADE_WAVES_LEAN) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                      const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
-                                                     double *acc, int32_t *prim_id_out, const uint32_t *group_base) {
+                                                     double *acc, int32_t *prim_id_out, const uint32_t *group_base,
+                                                     const uint32_t *child_base, uint32_t child_begin) {
     __shared__ uint32_t s_tmp[8];
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool in_range = gid < count;
@@ -1914,25 +1976,40 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
         hit.t = hit_t[gid];
         hit.ref = hit_ref[gid];
     }
-    // the ray's shadow groups (one per light, all at the same index) in the compact queue: k_closest_retry / k_group_base
-    uint32_t gslot = 0u;
-    if (fr.shadow_samples != 0u && sc.n_lights > 0) {   // base of the workgroup + rank among its rays that hit (a ballot, one barrier)
+    // The ray's shadow groups (one per light, all at the same index) in the compact queue and its children in the pool, both in ray
+    // order: base of the workgroup (k_closest_retry / k_group_base) + rank within it (a ballot and a wave scan, one barrier).  What the
+    // ray spawns follows from the class of the prim it hit and its depth counters (spawn_counts: the same function the counting pass calls).
+    const bool is_hit = valid && hit.ref != REF_NONE;
+    const uint32_t cls = is_hit ? ref_class_of(sc, hit.ref) : 0u;
+    uint32_t n_reflect = 0u;
+    bool spawn_transmit = false;
+    uint32_t n_children = is_hit ? spawn_counts(cls, flags, fr.gloss_samples, &n_reflect, &spawn_transmit) : 0u;
+    uint32_t gslot = 0u, cs = 0u;
+    {
         const uint32_t ln = threadIdx.x & 63u, wv_ = threadIdx.x >> 6;
-        const unsigned long long hm = __ballot(valid && hit.ref != REF_NONE);
+        const unsigned long long hm = __ballot(is_hit);
+        uint32_t x = n_children;   // inclusive scan over the wave
+        if (__any(n_children != 0u)) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)x, off);
+                if ((int)ln >= off) x += y;
+            }
+        }
+        uint32_t before_g = (fr.shadow_samples != 0u && sc.n_lights > 0) ? group_base[blockIdx.x] : 0u;
+        uint32_t before_c = child_begin + child_base[blockIdx.x];
         if (ln == 0u) s_tmp[wv_] = (uint32_t)__popcll(hm);
+        if (ln == 63u) s_tmp[4u + wv_] = x;
         __syncthreads();
-        uint32_t before = group_base[blockIdx.x];
-        for (uint32_t q = 0; q < wv_; ++q) before += s_tmp[q];
-        gslot = before + (uint32_t)__popcll(hm & ((1ull << ln) - 1ull));
-        __syncthreads();   // (s_tmp is used again by block_alloc)
+        for (uint32_t q = 0; q < wv_; ++q) { before_g += s_tmp[q]; before_c += s_tmp[4u + q]; }
+        gslot = before_g + (uint32_t)__popcll(hm & ((1ull << ln) - 1ull));
+        cs = before_c + x - n_children;
     }
     uint32_t reflect_depth = (flags >> RAYF_REFLECT_SHIFT) & RAYF_DEPTH_MASK;
     uint32_t refract_depth = (flags >> RAYF_REFRACT_SHIFT) & RAYF_DEPTH_MASK;
     bool inside = (flags & RAYF_INSIDE) != 0u;
     uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
     Ray r = make_ray(o, d);
-
-    bool is_hit = valid && hit.ref != REF_NONE;
 
     // ---- full Intersection of the winning prim (recomputed: same arithmetic, same bits)
     V3 hn = v3(0, 0, 1), hp = v3(0, 0, 0);
@@ -1979,9 +2056,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     }
 
     // ---- miss: skybox / background (renderer.rs:139-144)
-    if (valid && !is_hit) {
-        V3 c = sc.has_skybox ? cubemap_color(sc, d) : v3(sc.background[0], sc.background[1], sc.background[2]);
-        acc_add(acc, sample, thr * c);
+    {
+        V3 c = v3(0.0, 0.0, 0.0);
+        if (valid && !is_hit) c = sc.has_skybox ? cubemap_color(sc, d) : v3(sc.background[0], sc.background[1], sc.background[2]);
+        acc_add_runs(acc, valid && !is_hit, sample, thr * c);
     }
 
     // ---- hit: local lighting (renderer.rs:110-119)
@@ -2006,9 +2084,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
             V3 smp = material_sample<GENERAL>(mh, n, iv, l);
 #endif
             w = thr * (v3(lt.color[0], lt.color[1], lt.color[2]) * smp);
-            if (fr.shadow_samples == 0u) acc_add(acc, sample, w);                        // renderer.rs:191: shadow = one
-            else emit = true;
+            emit = fr.shadow_samples != 0u;
         }
+        if (fr.shadow_samples == 0u) acc_add_runs(acc, is_hit, sample, w);               // renderer.rs:191: shadow = one
         if (fr.shadow_samples != 0u) count_rays(emit, counters->ray_slots[blockIdx.x % RTX_RAY_SLOTS] + RTX_RAY_SLOT_GROUPS + li);
         if (emit) {
             size_t qc = sq.cap;
@@ -2021,23 +2099,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     }
 
     // ---- global lighting: spawn the child trace() calls (renderer.rs:122-135, 148-186)
-    bool reflective = is_hit && m.kind != RTX_MAT_FLAT && m.k_sg > 0.0;
-    bool refractive = is_hit && m.kind != RTX_MAT_FLAT && m.k_tg > 0.0;
+    const bool reflective = (cls & RTX_CLS_REFLECT) != 0u, refractive = (cls & RTX_CLS_REFRACT) != 0u;   // (cls = 0 for a miss)
     double reflect_fresnel = 0.0;
     if (reflective || refractive) reflect_fresnel = fresnel_reflect(m.ior, iv, n, inside);
     double refract_fresnel = 1.0 - reflect_fresnel;
 
-    // a child whose depth counter reaches 0 returns zero at renderer.rs:106 and is not a ray
-    bool spawn_reflect = reflective && reflect_depth > 1u && refract_depth > 0u;
-    bool glossy = GENERAL && m.kind != RTX_MAT_FLAT && m.glossiness > F64_EPSILON;
-    bool spawn_transmit = refractive && refract_depth > 1u && reflect_depth > 0u;
-    uint32_t n_reflect = spawn_reflect ? (glossy ? fr.gloss_samples : 1u) : 0u;
-    uint32_t n_children = n_reflect + (spawn_transmit ? 1u : 0u);
-#ifdef RTX_ABL_SHADE_NOSPAWN
-    n_children = 0u; n_reflect = 0u; spawn_transmit = false;
-#endif
-    uint32_t cs = block_alloc(n_children, &counters->pool_tail, s_tmp);
-    if (n_children && cs + n_children > pool.cap) {
+    const bool spawn_reflect = n_reflect != 0u;
+    const bool glossy = GENERAL && (cls & RTX_CLS_GLOSSY) != 0u;
+    if (n_children && (uint64_t)cs + n_children > (uint64_t)pool.cap) {   // (k_group_base has raised the overflow flag: the host gives the frame up)
         counters->overflow = 1u;
         n_reflect = 0u;
         spawn_transmit = false;
@@ -2208,7 +2277,7 @@ DEV void shadow_kernel_body(const DScene &sc, const DFrame &fr, const DShadowQ &
         const unsigned long long clear = __ballot(valid && v.x != 0.0);
         const unsigned long long mine = tries >= 64u ? ~0ull : (((1ull << tries) - 1ull) << (ln & ~(tries - 1u)));
         const double n_clear = (double)__popcll(clear & mine);
-        if (valid && k == 0u) acc_add(acc, sample, w * scale(v3(n_clear, n_clear, n_clear), inv_tries));             // renderer.rs:220,118
+        acc_add_runs(acc, valid && k == 0u, sample, w * scale(v3(n_clear, n_clear, n_clear), inv_tries));             // renderer.rs:220,118
     } else if (pow2_tries) {
         // groups are lane-aligned (tries divides 64 and RTX_BLOCK): butterfly sum over the group
         for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
@@ -2216,9 +2285,9 @@ DEV void shadow_kernel_body(const DScene &sc, const DFrame &fr, const DShadowQ &
             v.y += __shfl_xor(v.y, (int)off);
             v.z += __shfl_xor(v.z, (int)off);
         }
-        if (valid && k == 0u) acc_add(acc, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
-    } else if (valid) {
-        acc_add(acc, sample, w * scale(v, inv_tries));
+        acc_add_runs(acc, valid && k == 0u, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
+    } else {
+        acc_add_runs(acc, valid, sample, w * scale(v, inv_tries));
     }
     if constexpr (!LOOP) return;
     }
@@ -3128,7 +3197,8 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 }
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
-                void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, RtxTraceNames *names) {
+                void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, uint32_t child_begin,
+                RtxTraceNames *names) {
     if (count == 0) return;
     RtxTraceNames nm;
     static_assert(MODE_CLOSEST == 0 && MODE_CLOSEST_REF == 1 && MODE_CLOSEST_BVH == 5 && MODE_CLOSEST_BVH_DEALT == 8, "the kernel names below");
@@ -3138,37 +3208,41 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     if (names) *names = nm;
     const bool want_groups = fr.shadow_samples != 0u && sc.n_lights > 0;   // the slots of the compact shadow queue
     const unsigned nb = grid_for(count);
+    // group_base: four arrays of nb words: hits per workgroup, their exclusive scan, children per workgroup, their exclusive scan
+    uint32_t *hit_count = want_groups ? group_base : nullptr, *hit_base = group_base + nb, *child_count = group_base + 2 * nb, *child_base = group_base + 3 * nb;
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER) {
-        hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+        hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
                            count, counters, hit_t, hit_ref);
-        if (want_groups) hipLaunchKernelGGL(k_group_count, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, hit_ref, count, group_base);
+        hipLaunchKernelGGL(k_group_count, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_ref, fr.gloss_samples,
+                           hit_count, child_count);
     } else
     {
         // (scenes with transmissive materials: rays run along the inside of thin shells and meet ten candidates each: the exact tests dealt
         // out over the wave, see traverse_bvh_dealt)
         if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK) && !sc.all_opaque)
-            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH_DEALT>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH_DEALT>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
                                count, counters, hit_t, hit_ref);
         else if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK))
-            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
                                count, counters, hit_t, hit_ref);
         else
-            hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
+            hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
                                counters, hit_t, hit_ref);
-        hipLaunchKernelGGL(k_closest_retry, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
-                           hit_ref, want_groups ? group_base : nullptr);
+        hipLaunchKernelGGL(k_closest_retry, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
+                           hit_ref, fr.gloss_samples, hit_count, child_count);
     }
     if (record_after_closest) (void)hipEventRecord((hipEvent_t)record_after_closest, (hipStream_t)stream);
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
-    if (want_groups)   // (after the waits: it writes the queue's group count)
-        hipLaunchKernelGGL(k_group_base, dim3(grid_for(nb)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, group_base, nb, group_base + nb, sq.count);
+    // (after the waits: it writes the queue's group count) also moves the pool's tail past the step's children
+    hipLaunchKernelGGL(k_group_base, dim3(grid_for(nb)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, hit_count, child_count, nb, hit_base, child_base,
+                       sq.count, child_begin, pool.cap, counters);
     if (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE))
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
-                           hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));
+        hipLaunchKernelGGL(k_shade<true>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin);
     else
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(count)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
-                           hit_ref, sq, counters, acc, prim_id_out, group_base + grid_for(count));
+        hipLaunchKernelGGL(k_shade<false>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin);
 }
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                         uint32_t tries, DCounters *counters, double *acc, bool coop_defer) {

@@ -549,12 +549,16 @@ void free_work(Work &w) {
     if (w.sq.retry) hipFree(w.sq.retry);
     if (w.sq.wide) hipFree(w.sq.wide);
     if (w.sq.count) hipFree(w.sq.count);
+    if (w.sq.res) hipFree(w.sq.res);
+    if (w.sq.sample0) hipFree(w.sq.sample0);
     if (w.sq2.f) hipFree(w.sq2.f);
     if (w.sq2.key) hipFree(w.sq2.key);
     if (w.sq2.sample) hipFree(w.sq2.sample);
     if (w.sq2.retry) hipFree(w.sq2.retry);
     if (w.sq2.wide) hipFree(w.sq2.wide);
     if (w.sq2.count) hipFree(w.sq2.count);
+    if (w.sq2.res) hipFree(w.sq2.res);
+    if (w.sq2.sample0) hipFree(w.sq2.sample0);
     for (hipStream_t a : w.aux)
         if (a) hipStreamDestroy(a);
     if (w.d_counters) hipFree(w.d_counters);
@@ -585,25 +589,29 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     }
     size_t nl = std::max<size_t>(s->lights.size(), 1);
     if (w.sq.cap < batch) {
-        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); hipFree(w.sq.wide); uint32_t *keep = w.sq.retry, *keep2 = w.sq.count; w.sq = DShadowQ(); w.sq.retry = keep; w.sq.count = keep2; }
+        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); hipFree(w.sq.wide); hipFree(w.sq.res); hipFree(w.sq.sample0); uint32_t *keep = w.sq.retry, *keep2 = w.sq.count; w.sq = DShadowQ(); w.sq.retry = keep; w.sq.count = keep2; }
         w.sq.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.key, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.sample, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.wide, nl * (1u + (size_t)batch)))) return st;
+        if ((st = dev_alloc(&w.sq.res, nl * 3 * (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq.sample0, (size_t)batch))) return st;
         if (!w.sq.retry && (st = dev_alloc(&w.sq.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         if (!w.sq.count && (st = dev_alloc(&w.sq.count, 16))) return st;
         w.sq.cap = batch;
     }
     if (w.sq2.cap < batch) {
-        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); hipFree(w.sq2.wide); uint32_t *keep = w.sq2.retry, *keep2 = w.sq2.count; w.sq2 = DShadowQ(); w.sq2.retry = keep; w.sq2.count = keep2; }
+        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); hipFree(w.sq2.wide); hipFree(w.sq2.res); hipFree(w.sq2.sample0); uint32_t *keep = w.sq2.retry, *keep2 = w.sq2.count; w.sq2 = DShadowQ(); w.sq2.retry = keep; w.sq2.count = keep2; }
         w.sq2.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq2.f, nl * 6 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.key, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.sample, nl * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.wide, nl * (1u + (size_t)batch)))) return st;
+        if ((st = dev_alloc(&w.sq2.res, nl * 3 * (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq2.sample0, (size_t)batch))) return st;
         if (!w.sq2.retry && (st = dev_alloc(&w.sq2.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         if (!w.sq2.count && (st = dev_alloc(&w.sq2.count, 16))) return st;
         w.sq2.cap = batch;
@@ -691,11 +699,11 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     const size_t nl = std::max<size_t>(n_lights, 1);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t fixed = up(sizeof(DCounters)) + up(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)) +
-                         up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 21 * 256 /* alignment of the arrays below */;
+                         up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 23 * 256 /* alignment of the arrays below */;
     // per ray of a batch: hit record 12 (+ 16 per workgroup for the queue and pool slots), pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
     // one entry per light in the list of groups left to the per-lane shadow kernel 4
     const size_t pool_per = std::max<uint64_t>(need.per_batch, 1 + (uint64_t)need.fanout);
-    const size_t per = 12 + 1 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4;
+    const size_t per = 12 + 1 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4 + nl * 24 + 4;   // (+ the lights' deferred results and the clean sample plane)
     if (fixed + per * RTX_BLOCK + nl * 8 + nl * 256 > RTX_STATIC_SCRATCH_BYTES)
         return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: this call needs " + std::to_string(fixed + per * RTX_BLOCK) +
                                        " bytes of workspace, the static device scratch holds " + std::to_string(RTX_STATIC_SCRATCH_BYTES) +
@@ -723,6 +731,8 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     v.sq.retry_cap = (uint32_t)batch;
     v.sq.retry = (uint32_t *)take(nl * (2 + 2 * batch) * sizeof(uint32_t));
     v.sq.wide = (uint32_t *)take(nl * (1 + batch) * sizeof(uint32_t));
+    v.sq.res = (double *)take(nl * 3 * batch * sizeof(double));
+    v.sq.sample0 = (uint32_t *)take(batch * sizeof(uint32_t));
     v.sq.count = (uint32_t *)take(sizeof(uint32_t));
     v.sq.cap = (uint32_t)batch;
     v.sq2 = v.sq;   // one launch after the other on the caller's stream: one queue is enough
@@ -890,9 +900,19 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     // read theirs.  The caller's stream joins w.aux[] before the resolve.
     const bool overlap = !(fr.flags & RTX_FLAG_SERIAL) && opt->shadow_samples > 0 && !s->lights.empty();
     const bool coop_defer = s->d.n_planes > 0 && s->coop_plain_frames == 0;   // (see rtx_scene::coop_plain_frames)
+    // Deferred accumulation (rtx_device.h: DShadowQ.res, k_accumulate) pays where the shadow launches are long and several lights share a ray's
+    // sample: measured sponza (2 sphere lights x 16 tries) 184.3 -> 179.6 ms; against it bunny (1 light, 1 try) 4.29 -> 4.52 ms, sibenik
+    // (3 lights x 4 tries) 8.83 -> 8.91 ms, heptoroid 440.9 -> 443.4 ms: one more launch per step on a chain that is launch-bound.
+    // RTX_DIRECT_ACC=1 / RTX_DEFER_ACC=1 force either (A/B).
+    uint32_t n_soft = 0;
+    for (const rtx_light &lt : s->lights) n_soft += lt.kind != RTX_LIGHT_POINT ? 1u : 0u;
+    const bool direct_acc = std::getenv("RTX_DIRECT_ACC") != nullptr ||
+                            (!(n_soft >= 2u && opt->shadow_samples >= 16u) && std::getenv("RTX_DEFER_ACC") == nullptr);
     bool coop_defer_ran = false;
-    // the shadow feelers of this frame run in k_shadow_coop<false> beside the next step's closest-hit / shade launches: k_shade's small instance
-    if (overlap && s->d.all_opaque && s->d.wide && !(fr.flags & RTX_FLAG_NO_COOP) && opt->shadow_samples % 16u == 0u && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) && !std::getenv("RTX_GENERAL_SHADE"))
+    // k_shade's small instance (96 VGPRs, spills) for frames whose shadow feelers run in k_shadow_coop<false> beside the next step's closest-hit /
+    // shade launches: it paid while every workgroup of k_shade waited for a returning atomic on the pool's tail (sponza 208.6 -> 204.6 ms);
+    // without that atomic the general instance is the faster one there too (185.3 against 191.5 ms).  Kept behind RTX_LEAN_SHADE=1 for A/B.
+    if (overlap && s->d.all_opaque && s->d.wide && !(fr.flags & RTX_FLAG_NO_COOP) && opt->shadow_samples % 16u == 0u && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) && std::getenv("RTX_LEAN_SHADE"))
         fr.flags |= RTX_FLAG_INTERNAL_SMALL_SHADE;
     hipEvent_t sq_free[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [queue][aux stream]
     size_t n_aux = std::min<size_t>(2, s->lights.size());
@@ -940,7 +960,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b)) || (st = next_event(&sp_c.mid))) return st;
             HIPCHECK(hipEventRecord(sp_c.a, stream));
         }
-        const DShadowQ &sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
+        DShadowQ sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
+        if (direct_acc) sq.res = nullptr;   // A/B: every shadow launch adds its results to the samples itself
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
                    overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace);
         ++launches_closest;
@@ -962,8 +983,10 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         // the shadow queue is compact (one group per ray that hit something, in ray order; its count is on the device): the launches
         // get the grid of all n rays of the step and blocks past the count leave at once
         if (opt->shadow_samples > 0) {
+            uint32_t deferred = 0u;   // lights whose launch stores its results for k_accumulate (rtx_device.h: rtx_shadow_defers)
             for (size_t li = 0; li < s->lights.size(); ++li) {
                 uint32_t tries = s->lights[li].kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;   // renderer.rs:194
+                if (sq.res && rtx_shadow_defers(tries)) deferred |= 1u << li;
                 hipStream_t sstream = overlap ? w.aux[li % n_aux] : stream;
                 Span sp_s{nullptr, nullptr, 1 + (int)li, nullptr};
                 if (timing) {   // one event pair per launch, so ms_shadow / launches_shadow is a kernel duration
@@ -977,6 +1000,17 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                     HIPCHECK(hipEventRecord(sp_s.b, sstream));
                     spans.push_back(sp_s);
                 }
+            }
+            // the step's local lighting goes to the samples once every light has answered: on the first shadow stream, after the second
+            if (deferred) {
+                hipStream_t astream = overlap ? w.aux[0] : stream;
+                if (overlap && n_aux > 1 && s->lights.size() > 1) {
+                    hipEvent_t ev_l = nullptr;
+                    if ((st = next_event(&ev_l))) return st;
+                    HIPCHECK(hipEventRecord(ev_l, w.aux[1]));
+                    HIPCHECK(hipStreamWaitEvent(astream, ev_l, 0));
+                }
+                rtxk_accumulate(astream, sq, (uint32_t)s->lights.size(), deferred, n, v.acc);
             }
         }
         if (noalloc) {

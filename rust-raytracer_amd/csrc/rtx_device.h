@@ -186,6 +186,9 @@ struct DShadowQ {
     uint32_t *sample;   // [n_lights][cap]
     uint32_t *retry;    // [n_lights][2 + 2 * retry_cap]: count, pad, then (feeler index, primary sample) pairs: the degenerate feelers
                         // of the light's launch, answered by k_shadow_retry with the all-f64 walk
+    double *res;        // [n_lights][3][cap]: what the light's shadow launch found for the group (shadow_intensity's return value), stored for
+                        // k_accumulate; NULL in the copy a launch gets: that launch adds weight * shadow to the sample itself (atomics)
+    uint32_t *sample0;  // [cap]: the group's primary sample once more (k_shadow_coop<MULTI> marks the per-light copies it is done with)
     uint32_t *count;    // one word: the groups of the step (the same for every light: a ray that hits emits one per light)
     uint32_t *wide;     // [n_lights][1 + cap]: count, then the queue groups k_shadow_coop<MULTI> leaves to the per-lane kernel that follows it
     uint32_t cap;
@@ -242,6 +245,10 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc,
                         bool coop_defer /* k_shadow_coop<false, true> where 16 tries or a multiple share a hit point: see the kernel */);
+// a launch with this many tries per hit point can store its groups' results for k_accumulate (a group then lies within one wave)
+inline bool rtx_shadow_defers(uint32_t tries) { return tries <= 64u && (tries & (tries - 1u)) == 0u; }
+// after the last light's shadow launch of a step: adds the deferred results of the lights in the mask to the samples (k_accumulate)
+void rtxk_accumulate(rtx_stream_t stream, DShadowQ sq, uint32_t n_lights, uint32_t lights, uint32_t n_groups, double *acc);
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out);
 void rtxk_nearest(rtx_stream_t stream, const DScene &sc, int64_t n, const double *origin, const double *direction,
                   int32_t *prim_id, double *t_out, uint32_t flags);

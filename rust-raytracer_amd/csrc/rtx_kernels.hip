@@ -1608,6 +1608,9 @@ DEV void acc_add(double *acc, uint32_t sample, V3 c) {
 #ifdef RTX_EXP_NOACC
     if (c.x > -1.0) return;   // timing experiment only (wrong images)
 #endif
+#ifdef RTX_EXP_NOATOMIC
+    if (c.x != 1.2345e300) return;   // timing experiment only (wrong images): the operands are fetched and multiplied, nothing is added
+#endif
     double *p = acc + (size_t)sample * 3;
     unsafeAtomicAdd(p + 0, c.x);   // global_atomic_add_f64 on gfx950
     unsafeAtomicAdd(p + 1, c.y);
@@ -1637,6 +1640,23 @@ DEV void acc_add_runs(double *acc, bool has, uint32_t sample, V3 c) {
         }
     }
     if (has && head) acc_add(acc, sample, c);
+}
+
+// What a shadow launch found for a queue group (shadow_intensity's return value, renderer.rs:220).  DEFERRED (sq.res != null): a plain
+// store into the queue; k_accumulate, launched after the step's last light, adds  sum over the lights of  weight * shadow  to the sample:
+// one set of atomics per ray instead of one per ray and light, issued by a kernel that does nothing else.  (The f64 atomics on the
+// 800 MB accumulator of a 1080p x 16 frame are executed at the memory side; issued from the shadow kernels they cost the sponza frame
+// 11 of k_shadow_coop's 164 ms.)  Else (launches whose tries are not a power of two, RTX_DIRECT_ACC=1): added at once.
+// Every lane of the wave must call it.
+DEV void shadow_result(const DShadowQ &sq, double *acc, uint32_t light, bool has, uint32_t group, uint32_t sample, V3 w, V3 shadow) {
+    if (sq.res) {
+        if (has) {
+            double *r = sq.res + (size_t)light * 3 * sq.cap + group;
+            r[0] = shadow.x; r[sq.cap] = shadow.y; r[2 * (size_t)sq.cap] = shadow.z;
+        }
+    } else {
+        acc_add_runs(acc, has, sample, w * shadow);
+    }
 }
 
 // sample index -> pixel: samples are laid out so that one wave64 = one 8x8 pixel tile of one
@@ -2091,6 +2111,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
         if (emit) {
             size_t qc = sq.cap;
             sq.sample[(size_t)li * qc + gslot] = sample;
+            if (li == 0 && sq.sample0) sq.sample0[gslot] = sample;
             double *f = sq.f + (size_t)li * 6 * qc + gslot;
             f[0 * qc] = hp.x; f[1 * qc] = hp.y; f[2 * qc] = hp.z;
             f[3 * qc] = w.x; f[4 * qc] = w.y; f[5 * qc] = w.z;
@@ -2277,7 +2298,7 @@ DEV void shadow_kernel_body(const DScene &sc, const DFrame &fr, const DShadowQ &
         const unsigned long long clear = __ballot(valid && v.x != 0.0);
         const unsigned long long mine = tries >= 64u ? ~0ull : (((1ull << tries) - 1ull) << (ln & ~(tries - 1u)));
         const double n_clear = (double)__popcll(clear & mine);
-        acc_add_runs(acc, valid && k == 0u, sample, w * scale(v3(n_clear, n_clear, n_clear), inv_tries));             // renderer.rs:220,118
+        shadow_result(sq, acc, light, valid && k == 0u, group, sample, w, scale(v3(n_clear, n_clear, n_clear), inv_tries));   // renderer.rs:220,118
     } else if (pow2_tries) {
         // groups are lane-aligned (tries divides 64 and RTX_BLOCK): butterfly sum over the group
         for (uint32_t off = tries >> 1; off > 0; off >>= 1) {
@@ -2285,9 +2306,9 @@ DEV void shadow_kernel_body(const DScene &sc, const DFrame &fr, const DShadowQ &
             v.y += __shfl_xor(v.y, (int)off);
             v.z += __shfl_xor(v.z, (int)off);
         }
-        acc_add_runs(acc, valid && k == 0u, sample, w * scale(v, inv_tries));             // renderer.rs:220,118
+        shadow_result(sq, acc, light, valid && k == 0u, group, sample, w, scale(v, inv_tries));   // renderer.rs:220,118
     } else {
-        acc_add_runs(acc, valid, sample, w * scale(v, inv_tries));
+        acc_add_runs(acc, valid, sample, w * scale(v, inv_tries));   // (the host launches these with sq.res = null: a group's tries span waves)
     }
     if constexpr (!LOOP) return;
     }
@@ -3026,12 +3047,51 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     uint32_t t2 = threadIdx.x;
     asm volatile("" : "+v"(t2));   // group / try index and loads afresh, not the prologue's values kept alive
     const uint64_t gid2 = (uint64_t)blockIdx.x * RTX_BLOCK + t2;
+    if (pow2_tries && tries >= 4u) {
+        // the three components of a group's result belong to its first three lanes: one store / atomic instruction per wave instead of three
+        const uint32_t kk = (uint32_t)gid2 & (tries - 1u);
+        if (valid && !wide && kk < 3u) {
+            const uint32_t g2 = (uint32_t)(gid2 >> tries_shift);
+            if (sq.res) {   // deferred: k_accumulate multiplies with the weight and adds (shadow_result)
+                sq.res[((size_t)light * 3 + kk) * qc + g2] = v.x * inv_tries;
+            } else {
+                const double wk = sq.f[(size_t)light * 6 * qc + (size_t)(3u + kk) * qc + g2];
+                unsafeAtomicAdd(acc + (size_t)sq.sample[(size_t)light * qc + g2] * 3 + kk, wk * (v.x * inv_tries));   // renderer.rs:220,118
+            }
+        }
+        if (MULTI) {   // done: the per-lane pass that follows skips the group (after its three lanes have read the sample)
+            __builtin_amdgcn_wave_barrier();
+            if (valid && !wide && kk == 0u) sq.sample[(size_t)light * qc + (uint32_t)(gid2 >> tries_shift)] = SHADOW_GROUP_EMPTY;
+        }
+    } else
     if (valid && !wide && (!pow2_tries || ((uint32_t)gid2 & (tries - 1u)) == 0u)) {
         const uint32_t g2 = pow2_tries ? (uint32_t)(gid2 >> tries_shift) : (uint32_t)(gid2 / tries);
         const double *f = sq.f + (size_t)light * 6 * qc + g2;
         acc_add(acc, sq.sample[(size_t)light * qc + g2], v3(f[3 * qc], f[4 * qc], f[5 * qc]) * scale(v, inv_tries));   // renderer.rs:220,118
         if (MULTI) sq.sample[(size_t)light * qc + g2] = SHADOW_GROUP_EMPTY;   // done: the per-lane pass that follows skips it
     }
+}
+
+// The local lighting of a step's rays, added to their samples once every light's shadow launch has stored its result (shadow_result):
+// light.color() * material.sample() * shadow, summed over the lights in their order (the fold of renderer.rs:114-119; the weight carries
+// the path's throughput).  `lights`: bit li = light li's launch has deferred its results (the others have added theirs themselves).
+__global__ void __launch_bounds__(RTX_BLOCK) k_accumulate(DShadowQ sq, uint32_t n_lights, uint32_t lights, double *acc) {
+    const uint32_t g = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    const uint32_t n = *sq.count;
+    if (blockIdx.x * RTX_BLOCK >= n) return;   // (the whole workgroup)
+    const bool has = g < n;
+    const size_t qc = sq.cap;
+    V3 c = v3(0.0, 0.0, 0.0);
+    uint32_t sample = 0u;
+    if (has) {
+        sample = sq.sample0[g];
+        for (uint32_t li = 0; li < n_lights; ++li) {
+            if (!((lights >> li) & 1u)) continue;
+            const double *f = sq.f + (size_t)li * 6 * qc + g, *r = sq.res + (size_t)li * 3 * qc + g;
+            c = c + v3(f[3 * qc], f[4 * qc], f[5 * qc]) * v3(r[0], r[qc], r[2 * qc]);
+        }
+    }
+    acc_add_runs(acc, has, sample, c);
 }
 
 // K6 resolve: per-sample clamp + average (renderer.rs:95) and ColorRGBA::new_rgb_clamped
@@ -3248,6 +3308,7 @@ const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr,
                         uint32_t tries, DCounters *counters, double *acc, bool coop_defer) {
     if (n_groups == 0 || tries == 0) return "";
     uint32_t pow2 = (tries <= 64u && (tries & (tries - 1u)) == 0u) ? 1u : 0u;
+    if (!rtx_shadow_defers(tries)) sq.res = nullptr;   // (a group's tries span waves: every lane adds its own share, shadow_kernel_body)
     uint64_t lanes = (uint64_t)n_groups * tries;
     // the cooperative walk pays off when the 16 rays of a group form a narrow beam: the feelers of ONE hit
     // point towards one light (tries a multiple of 16); groups mixing hit points can be arbitrarily
@@ -3423,6 +3484,10 @@ void *rtxk_static_scratch(int device, int *hip_error) {
     return ptr;
 }
 
+void rtxk_accumulate(rtx_stream_t stream, DShadowQ sq, uint32_t n_lights, uint32_t lights, uint32_t n_groups, double *acc) {
+    if (n_groups == 0 || lights == 0u) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(n_groups)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sq, n_lights, lights, acc);
+}
 void rtxk_resolve(rtx_stream_t stream, const DFrame &fr, const double *acc, uint8_t *rgba_out) {
     uint64_t n_pix = (uint64_t)fr.n_blocks_local * fr.tiles_x * 64u;
     if (n_pix == 0) return;

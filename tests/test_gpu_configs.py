@@ -201,3 +201,35 @@ def test_soft_shadows_on_a_ground_plane_that_runs_to_the_horizon(rtx, orc, tries
     assert (oids == int(oids.max())).mean() > 0.2                          # the plane (last prim id) fills a good part of the frame
     if tries != 48:
         assert st.ms_shadow <= 3.0 * st_lane.ms_shadow + 0.5, (st.ms_shadow, st_lane.ms_shadow)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mesh", "mesh_transmissive", "kitchen"])
+@pytest.mark.parametrize("tries", [1, 4, 16, 48])
+def test_deferred_accumulation_equals_direct(rtx, orc, which, tries, monkeypatch):
+    """Where several soft lights share a ray's sample and the shadow launches are long (two sphere lights, 16 tries and more) the shadow
+    kernels store each group's result and k_accumulate adds  sum over the lights of weight x shadow  to the sample, one set of atomics
+    per ray (DShadowQ.res); elsewhere every launch adds its own.  RTX_DEFER_ACC / RTX_DIRECT_ACC force either: same rays, same
+    products, the images differ at most by the order of f64 additions; the deferred frame is also held against the oracle.
+    Small batches: many steps, both queues in turn.  48 tries: that launch adds for itself (a group spans waves), the others defer."""
+    if which == "kitchen":
+        flat, cam_fn = scenes.kitchen_sink_scene(rtx)
+    else:
+        flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=(which == "mesh_transmissive"))
+    cam = cam_fn(160, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=4, refract_depth=4, shadow_samples=tries, pixel_samples=2, rng_mode=1, seed=11, batch_rays=8192)
+    monkeypatch.setenv("RTX_DEFER_ACC", "1")
+    a, ia, sa = sc.render(cam, rtx.options(**kw))
+    a2, ia2, sa2 = sc.render(cam, rtx.options(flags=rtx.abi.FLAG_SERIAL, **kw))
+    monkeypatch.delenv("RTX_DEFER_ACC")
+    monkeypatch.setenv("RTX_DIRECT_ACC", "1")
+    b, ib, sb = sc.render(cam, rtx.options(**kw))
+    monkeypatch.delenv("RTX_DIRECT_ACC")
+    sc.close()
+    o, io, so = orc.Scene(flat).render(cam, rtx.options(**kw), threads=16)
+    for x, ix, sx in ((a, ia, sa), (a2, ia2, sa2), (b, ib, sb)):
+        assert np.array_equal(ix, io) and sx.rays_total == so.rays_total
+        assert (np.abs(x[..., :3].astype(int) - o[..., :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3
+    assert (np.abs(a.astype(int) - a2.astype(int)) <= 1).all()

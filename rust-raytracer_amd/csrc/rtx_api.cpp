@@ -1415,6 +1415,14 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
     ds.entries32 = d_entries32;
     lap("rest of the uploads");
     rtxk_build_twins(nullptr, ds.nodes, d_nodes32, (int64_t)n_nodes, ds.leaf_refs, ds.tris, ds.spheres, d_entries32, (int64_t)leaf_refs.size(), centre);
+    if (ds.prim_leaves) {
+        DNode32 *d_leaf_boxes = nullptr;
+        if ((st = dev_alloc(&d_leaf_boxes, prim_leaves.size()))) return cleanup(st);
+        s->allocs.push_back(d_leaf_boxes);
+        s->info.device_bytes += (int64_t)(std::max<size_t>(prim_leaves.size(), 1) * sizeof(DNode32));
+        rtxk_build_leaf_boxes(nullptr, d_nodes32, ds.prim_leaves, d_leaf_boxes, (int64_t)prim_leaves.size());
+        ds.prim_leaf_boxes = d_leaf_boxes;
+    }
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipGetLastError());
     lap("f32 twins (device)");

@@ -120,6 +120,7 @@ struct DScene {
     // prim_leaf_begin[id + 1]); built for scenes with transmissive materials only (the two-phase shadow product), else NULL
     const int32_t *prim_leaf_begin;
     const int32_t *prim_leaves;
+    const DNode32 *prim_leaf_boxes;   // [e] = nodes32[prim_leaves[e]]: a prim's leaf boxes as one run of 32-byte records (built on the device)
     uint32_t bvh4_node_bits;    // bits of a stack entry that hold the node index (the rest: quantised entry distance)
     uint32_t shade_features;    // RTX_SHADE_*: what the scene's materials need of k_shade (0: the lean instance)
     const DTri *tris;
@@ -256,6 +257,7 @@ void rtxk_shadow_products(rtx_stream_t stream, const DScene &sc, int64_t n, cons
                           double *out, uint32_t flags);
 // scene build, on the device: the conservative f32 twins of the octree (DNode32 per node, DEntry32 per leaf entry: the entry's prim box
 // recomputed from the prim record) from the uploaded f64 records; boxes relative to `centre`, rounded outward
+void rtxk_build_leaf_boxes(rtx_stream_t stream, const DNode32 *nodes32, const int32_t *prim_leaves, DNode32 *out, int64_t n);
 void rtxk_build_twins(rtx_stream_t stream, const DNode *nodes, DNode32 *nodes32, int64_t n_nodes, const int32_t *leaf_refs,
                       const DTri *tris, const DSphere *spheres, DEntry32 *entries32, int64_t n_entries, const double centre[3]);
 void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out);

@@ -1150,27 +1150,37 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
 #endif
                 m = 0u;
                 const int e0 = sc.prim_leaf_begin[pid], e1 = sc.prim_leaf_begin[pid + 1];
-                for (int e = e0; e < e1; ++e) {
-                    const uint32_t leaf = (uint32_t)sc.prim_leaves[e];
-                    const float4 *nq = reinterpret_cast<const float4 *>(sc.nodes32 + leaf);
-                    const float4 qa = nq[0], qb = nq[1];
+                // the f32 boxes of the prim's leaves lie NEXT TO EACH OTHER in prim_leaf_boxes (copies of their nodes32 records, in the order of
+                // prim_leaves): a run of 32-byte records instead of an index and a scattered record per leaf, fetched two at a time
+                auto leaf_reached = [&](int e, const float4 &qa, const float4 &qb) -> uint32_t {
                     const float pnx = r.sx ? qa.x : qa.w, pfx = r.sx ? qa.w : qa.x;
                     const float pny = r.sy ? qa.y : qb.x, pfy = r.sy ? qb.x : qa.y;
                     const float pnz = r.sz ? qa.z : qb.y, pfz = r.sz ? qb.y : qa.z;
                     // the box widened by delta missed => the f64 test fails (as the octree walk descends)
                     const float lo = fmaxf(fmaxf(fmaxf(fmaf(pnx, ix, cnx), 0.0f), fmaf(pny, iy, cny)), fmaf(pnz, iz, cnz));
                     const float hi = fminf(fminf(fmaf(pfx, ix, cfx), fmaf(pfy, iy, cfy)), fmaf(pfz, iz, cfz));
-                    if (!(lo <= hi)) continue;
+                    if (!(lo <= hi)) return 0u;
                     // the box shrunk by delta passed => the f64 test passes; in between: the reference's test on the stored box
                     bool reached = surely_hit(fmaf(pnx, ix, cfx), fmaf(pny, iy, cfy), fmaf(pnz, iz, cfz), fmaf(pfx, ix, cnx), fmaf(pfy, iy, cny),
                                               fmaf(pfz, iz, cnz));
                     if (!reached) {
-                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + leaf);
+                        const double2 *dq = reinterpret_cast<const double2 *>(sc.nodes + (uint32_t)sc.prim_leaves[e]);
                         const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2];
                         double tn, tf;
                         reached = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r, &tn, &tf);
                     }
-                    m += reached ? 1u : 0u;
+                    return reached ? 1u : 0u;
+                };
+                const float4 *lb = reinterpret_cast<const float4 *>(sc.prim_leaf_boxes);
+                int e = e0;
+                for (; e + 1 < e1; e += 2) {
+                    const float4 a0 = lb[2 * e], a1 = lb[2 * e + 1], b0 = lb[2 * e + 2], b1 = lb[2 * e + 3];
+                    m += leaf_reached(e, a0, a1);
+                    m += leaf_reached(e + 1, b0, b1);
+                }
+                if (e < e1) {
+                    const float4 a0 = lb[2 * e], a1 = lb[2 * e + 1];
+                    m += leaf_reached(e, a0, a1);
                 }
             }
             const rtx_material &mt = sc.materials[mat];
@@ -3439,6 +3449,14 @@ void rtxk_build_twins(rtx_stream_t stream, const DNode *nodes, DNode32 *nodes32,
     if (n_entries > 0)
         hipLaunchKernelGGL(k_build_entries32, dim3(grid_for((uint64_t)n_entries)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, leaf_refs, tris,
                            spheres, entries32, n_entries, centre[0], centre[1], centre[2]);
+}
+// prim_leaf_boxes[e] = nodes32[prim_leaves[e]] (phase 2 of the two-phase shadow product reads a prim's leaf boxes as one run)
+__global__ void __launch_bounds__(RTX_BLOCK) k_build_leaf_boxes(const DNode32 *nodes32, const int32_t *prim_leaves, DNode32 *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (i < n) out[i] = nodes32[prim_leaves[i]];
+}
+void rtxk_build_leaf_boxes(rtx_stream_t stream, const DNode32 *nodes32, const int32_t *prim_leaves, DNode32 *out, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(k_build_leaf_boxes, dim3(grid_for((uint64_t)n)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, nodes32, prim_leaves, out, n);
 }
 void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out) {
     if (n <= 0) return;

@@ -197,3 +197,17 @@ def test_draw3_is_one_philox_block(orc):
     d = orc.draw3(1, key, 1, 2, 3)
     assert d.tolist() == [(int(w) + 0.5) / 4294967296.0 for w in words[:3]]
     assert all(0.0 < x < 1.0 for x in d)
+
+
+def test_u8_over_255_without_the_division():
+    """ColorRGBA channels are p / 255.0 (colorrgba.rs:116-124).  k_shade computes them as q = p * RN(1 / 255), q + fma(-255, q, p) * RN(1 / 255)
+    (rtx_kernels.hip: u8_over_255): for every one of the 256 arguments that is the correctly rounded quotient, bit for bit.  The two
+    FMAs are evaluated exactly here (rationals, one rounding each)."""
+    from fractions import Fraction
+    c = 1.0 / 255.0
+    assert c.hex() == "0x1.0101010101010p-8"
+    for p in range(256):
+        q = float(p) * c
+        r = float(Fraction(p) - 255 * Fraction(q))                    # fma(-255, q, p): one rounding
+        got = float(Fraction(q) + Fraction(r) * Fraction(c))           # fma(r, c, q)
+        assert got == p / 255.0 and got.hex() == (p / 255.0).hex(), p

@@ -1,5 +1,7 @@
 #!/bin/bash
 # every kernel alone (serial frame) for ablation builds of k_shade (timing only, wrong images): shade_abl.sh "sponza bunny" base nosky notri ...
+# (the -DRTX_ABL_SPAWN_* / -DRTX_ABL_SHADE_NO{SKY,TRI,TEX} switches these variants were built with were removed from rtx_kernels.hip after the
+#  experiment: git show 5536f8d..1781f2d; the results are in DESIGN.md section 11)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 WL=$1; shift

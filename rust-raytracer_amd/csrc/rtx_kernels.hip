@@ -1995,8 +1995,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     bool in_range = gid < count;
     bool valid = in_range;
     uint32_t slot = begin + (valid ? gid : 0u);
+    // The kernel waits for its fetches at 2 waves per SIMD, so what can be in flight together is asked for together: the ray's record
+    // and hit with its flags (a dead ray's slot holds a ray all the same), then, below, the prim's class and its two records.
     uint32_t flags = valid ? pool.flags[slot] : RAYF_DEAD;
-    valid = valid && !(flags & RAYF_DEAD);
 
     size_t cap = pool.cap;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(0, 0, 0);
@@ -2005,7 +2006,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     Hit hit;
     hit.t = inf();
     hit.ref = REF_NONE;
-    if (valid) {
+    if (in_range) {
         const double *f = pool.f + slot;
         o = v3(f[0 * cap], f[1 * cap], f[2 * cap]);
         d = v3(f[3 * cap], f[4 * cap], f[5 * cap]);
@@ -2015,10 +2016,21 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
         hit.t = hit_t[gid];
         hit.ref = hit_ref[gid];
     }
+    valid = valid && !(flags & RAYF_DEAD);
+    if (!valid) { o = v3(0, 0, 0); d = v3(0, 0, 1); thr = v3(0, 0, 0); key = 0; sample = 0; hit.t = inf(); hit.ref = REF_NONE; }
     // The ray's shadow groups (one per light, all at the same index) in the compact queue and its children in the pool, both in ray
     // order: base of the workgroup (k_closest_retry / k_group_base) + rank within it (a ballot and a wave scan, one barrier).  What the
     // ray spawns follows from the class of the prim it hit and its depth counters (spawn_counts: the same function the counting pass calls).
     const bool is_hit = valid && hit.ref != REF_NONE;
+    const bool is_tri = is_hit && hit.ref >= 0 && !(hit.ref & REF_PLANE);
+    double2 tv[5] = {}, ts[8] = {};   // the triangle's vertex and shading records, asked for before the barrier below (used after it)
+    if (is_tri) {
+        const double2 *p5 = reinterpret_cast<const double2 *>(sc.tris + hit.ref), *p8 = reinterpret_cast<const double2 *>(sc.tri_shade + hit.ref);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) tv[k] = p5[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ts[k] = p8[k];
+    }
     const uint32_t cls = is_hit ? ref_class_of(sc, hit.ref) : 0u;
     uint32_t n_reflect = 0u;
     bool spawn_transmit = false;
@@ -2057,13 +2069,18 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     if (is_hit) {
         double t = hit.t;
         hp = o + scale(d, t);                                                            // origin + direction.scale(t)
-        if (hit.ref >= 0 && !(hit.ref & REF_PLANE)) {                                    // triangle.rs:136-145
-            TriV tr = load_tri(sc.tris, hit.ref, &prim_id, &material);
+        if (is_tri) {                                                                    // triangle.rs:136-145
+            TriV tr;   // (as load_tri)
+            tr.v0 = v3(tv[0].x, tv[0].y, tv[1].x);
+            tr.v1 = v3(tv[1].y, tv[2].x, tv[2].y);
+            tr.v2 = v3(tv[3].x, tv[3].y, tv[4].x);
+            const long long ids = __double_as_longlong(tv[4].y);
+            prim_id = (int)(ids & 0xFFFFFFFFLL);
+            material = (int)(ids >> 32);
             double tt, beta, gamma;
             tri_hit(tr, r, -inf(), inf(), &tt, &beta, &gamma);
             double alpha = 1.0 - beta - gamma;
-            const double2 *sp2 = reinterpret_cast<const double2 *>(sc.tri_shade + hit.ref);
-            double2 a0 = sp2[0], a1 = sp2[1], a2 = sp2[2], a3 = sp2[3], a4 = sp2[4], a5 = sp2[5], a6 = sp2[6], a7 = sp2[7];
+            double2 a0 = ts[0], a1 = ts[1], a2 = ts[2], a3 = ts[3], a4 = ts[4], a5 = ts[5], a6 = ts[6], a7 = ts[7];
             V3 n0 = v3(a0.x, a0.y, a1.x), n1 = v3(a1.y, a2.x, a2.y), n2 = v3(a3.x, a3.y, a4.x);
             double u0 = a4.y, v0 = a5.x, u1 = a5.y, v1 = a6.x, u2 = a6.y, v2 = a7.x;
             hn = scale(n0, alpha) + scale(n1, beta) + scale(n2, gamma);

@@ -948,13 +948,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             if (n == 0) return fail(RTX_ERR_QUEUE_OVERFLOW, "ray pool exhausted; raise rtx_options.pool_rays");
         }
         uint32_t begin = top.end - n;
-        if (noalloc) {
-            rtxk_set_pool_tail(stream, v.d_counters, top_end);
-        } else {
-            w.h_up->pool_tail = top_end;
-            w.h_up->overflow = 0;
-            HIPCHECK(hipMemcpyAsync(v.d_counters, w.h_up, offsetof(DCounters, ray_slots), hipMemcpyHostToDevice, stream));
-        }
+        // (the pool's tail needs no upload: k_group_base moves it from top_end, which rtxk_trace hands it, past the step's children; the
+        // overflow flag was cleared with the frame's counters and ends the frame the first time it is raised)
         Span sp_c{nullptr, nullptr, 0, nullptr};
         if (timing) {
             if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b)) || (st = next_event(&sp_c.mid))) return st;

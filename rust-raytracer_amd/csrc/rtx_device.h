@@ -263,7 +263,6 @@ void rtxk_build_twins(rtx_stream_t stream, const DNode *nodes, DNode32 *nodes32,
 void rtxk_shade_probe(rtx_stream_t stream, const DScene &sc, int which, int64_t n, const double *in, double *out);
 // sets counters->pool_tail, clears counters->overflow (a one-thread kernel: the allocation-free entry point has no pinned
 // host buffer to copy them from)
-void rtxk_set_pool_tail(rtx_stream_t stream, DCounters *counters, uint32_t pool_tail);
 // zeroes the whole record and sets its ray_slots pointer (same reason)
 void rtxk_init_counters(rtx_stream_t stream, DCounters *counters, unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS]);
 // The static device scratch of rtx_render_device_noalloc: a file-scope __device__ array in rtx_kernels.hip.  Resolves (once per

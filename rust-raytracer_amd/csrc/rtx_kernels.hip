@@ -3420,10 +3420,6 @@ const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr,
         hipLaunchKernelGGL(k_shadow_retry, dim3(64), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, tries, acc);
     return name;
 }
-__global__ void k_set_pool_tail(DCounters *counters, uint32_t pool_tail) {
-    counters->pool_tail = pool_tail;
-    counters->overflow = 0u;
-}
 // Scene build on the device: DNode32 / DEntry32 (see rtx_device.h) from the f64 records.  v_cvt_f32_f64 with directed rounding
 // (toward -inf for a box's lower corner, toward +inf for its upper corner) is the outward rounding the conservative tests rely on.
 __global__ void __launch_bounds__(RTX_BLOCK) k_build_nodes32(const DNode *nodes, DNode32 *out, int64_t n, double cx, double cy, double cz) {
@@ -3495,9 +3491,6 @@ __global__ void k_init_counters(DCounters *counters, unsigned long long (*ray_sl
 }
 void rtxk_init_counters(rtx_stream_t stream, DCounters *counters, unsigned long long (*ray_slots)[RTX_RAY_SLOT_WORDS]) {
     hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(1), 0, (hipStream_t)stream, counters, ray_slots);
-}
-void rtxk_set_pool_tail(rtx_stream_t stream, DCounters *counters, uint32_t pool_tail) {
-    hipLaunchKernelGGL(k_set_pool_tail, dim3(1), dim3(1), 0, (hipStream_t)stream, counters, pool_tail);
 }
 
 // The workspace of rtx_render_device_noalloc (rtx.h): ray pool, shadow queue, hit records, counters and sample accumulators of

@@ -3086,6 +3086,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     if (pow2_tries && tries >= 4u) {
         // the three components of a group's result belong to its first three lanes: one store / atomic instruction per wave instead of three
         const uint32_t kk = (uint32_t)gid2 & (tries - 1u);
+#ifdef RTX_COUNT_OCCL   // experiment (tools/exp/occl_count.py): groups with every feeler occluded / every feeler clear / mixed, in rtx_stats.work[0]
+        if (valid && !wide && kk == 0u) atomicAdd(&counters->work[0][v.x == 0.0 ? 0 : (v.x == (double)tries ? 1 : 2)], 1ull);
+#endif
         if (valid && !wide && kk < 3u) {
             const uint32_t g2 = (uint32_t)(gid2 >> tries_shift);
             if (sq.res) {   // deferred: k_accumulate multiplies with the weight and adds (shadow_result)

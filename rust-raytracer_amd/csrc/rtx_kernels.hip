@@ -919,11 +919,16 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
         if (!__any(running || cnt > 0u)) break;
         for (int step = 0; step < RTX_BVH_STEPS && running && cnt <= RTX_BVH_CAND - RTX_BVH4; ++step) {
             if (!have_cur) {
-                if (sp == 0u) { running = false; break; }
-                --sp;
-                const uint32_t e = stk[sp * RTX_BLOCK];
-                if (!ANY && (float)(e >> nbits) * qinv > bf) continue;   // it starts behind the best hit
-                cur = e & nmask;
+                // the next stack entry that does not start behind the best hit: popped in a loop of its own (a culled entry used to cost
+                // the lane one whole node step of the wave; once a ray has its hit, most of what its stack still holds is culled):
+                // k_closest<5> sponza 14.85 -> 14.54 ms, sibenik 1.01 -> 0.98 ms
+                bool got = false;
+                while (sp > 0u) {
+                    --sp;
+                    const uint32_t e = stk[sp * RTX_BLOCK];
+                    if (ANY || !((float)(e >> nbits) * qinv > bf)) { cur = e & nmask; got = true; break; }
+                }
+                if (!got) { running = false; break; }
             }
             have_cur = false;
             WORK(++w_nodes;)
@@ -1296,7 +1301,7 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
                 else {
                     --sp;
                     const uint32_t e = stk[sp * RTX_BLOCK];
-                    if (CLOSEST && (float)(e >> nbits) * qinv > bf) visit = false;   // it starts behind the best hit
+                    if (CLOSEST && (float)(e >> nbits) * qinv > bf) visit = false;   // it starts behind the best hit (popping on in a loop of its own, as traverse_bvh does: heptoroid closest hit 147.3 -> 155.5 ms)
                     else cur = e & nmask;
                 }
             }

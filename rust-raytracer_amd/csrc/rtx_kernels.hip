@@ -2628,9 +2628,18 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
     const bool neg0 = a0 == 0 ? gneg[0] : (a0 == 1 ? gneg[1] : gneg[2]);
     // u = s0 * (coord - origin), s0 = +-1; origin interval along a0, widened below
     float o0min, o0max, o1min, o1max, o2min, o2max, m1L, m1H, m2L, m2H;
-    grp_min_max(walk ? f32_below(o0) : INF, walk ? f32_above(o0) : -INF, &o0min, &o0max);
-    grp_min_max(walk ? f32_below(o1) : INF, walk ? f32_above(o1) : -INF, &o1min, &o1max);
-    grp_min_max(walk ? f32_below(o2) : INF, walk ? f32_above(o2) : -INF, &o2min, &o2max);
+    // One hit point per group and no feeler re-based to its entry into the scene's cube (always, but for hit points on planes outside it):
+    // the 16 origins of a group are one point and need no reduction (a scalar branch; a group without a walker then holds a finite beam
+    // instead of an empty one, and does not walk either way)
+    if (!MULTI && __all(tsh == 0.0)) {
+        o0min = f32_below(o0); o0max = f32_above(o0);
+        o1min = f32_below(o1); o1max = f32_above(o1);
+        o2min = f32_below(o2); o2max = f32_above(o2);
+    } else {
+        grp_min_max(walk ? f32_below(o0) : INF, walk ? f32_above(o0) : -INF, &o0min, &o0max);
+        grp_min_max(walk ? f32_below(o1) : INF, walk ? f32_above(o1) : -INF, &o1min, &o1max);
+        grp_min_max(walk ? f32_below(o2) : INF, walk ? f32_above(o2) : -INF, &o2min, &o2max);
+    }
     // A group whose origins are spread out (MULTI: its hit points; one hit point: a point OUTSIDE the scene's cube, on a plane that
     // runs to the horizon, whose feelers enter the cube far apart: the origins above are the entry points) or whose feelers point in
     // mixed directions makes a beam that touches much of the hierarchy: it is left to the per-lane kernel that runs next, through the

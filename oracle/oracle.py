@@ -160,7 +160,10 @@ class Scene:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_scene_destroy(self.h)
+            try:
+                lib().orc_scene_destroy(self.h)
+            except TypeError:   # interpreter shutdown: the module's globals are gone already
+                pass
             self.h = None
 
     def octree_info(self):

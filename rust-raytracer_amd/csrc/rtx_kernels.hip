@@ -1626,6 +1626,8 @@ DEV void acc_add(double *acc, uint32_t sample, V3 c) {
 #ifdef RTX_EXP_NOATOMIC
     if (c.x != 1.2345e300) return;   // timing experiment only (wrong images): the operands are fetched and multiplied, nothing is added
 #endif
+    // (a zero leaves the sum as it is: no atomic for it.  Half of a frame's shadow groups are fully occluded: tools/exp/occl_count.py)
+    if (c.x == 0.0 && c.y == 0.0 && c.z == 0.0) return;
     double *p = acc + (size_t)sample * 3;
     unsafeAtomicAdd(p + 0, c.x);   // global_atomic_add_f64 on gfx950
     unsafeAtomicAdd(p + 1, c.y);
@@ -3109,7 +3111,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
                 sq.res[((size_t)light * 3 + kk) * qc + g2] = v.x * inv_tries;
             } else {
                 const double wk = sq.f[(size_t)light * 6 * qc + (size_t)(3u + kk) * qc + g2];
-                unsafeAtomicAdd(acc + (size_t)sq.sample[(size_t)light * qc + g2] * 3 + kk, wk * (v.x * inv_tries));   // renderer.rs:220,118
+                const double add = wk * (v.x * inv_tries);                                                  // renderer.rs:220,118
+                // (a zero leaves the sum as it is: no atomic for a fully occluded group; a NaN or infinite weight times zero is a NaN, as in the reference, and is added)
+                if (add != 0.0) unsafeAtomicAdd(acc + (size_t)sq.sample[(size_t)light * qc + g2] * 3 + kk, add);
             }
         }
         if (MULTI) {   // done: the per-lane pass that follows skips the group (after its three lanes have read the sample)

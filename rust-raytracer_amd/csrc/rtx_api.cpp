@@ -1366,12 +1366,13 @@ rtx_status rtx_scene_create(const rtx_scene_desc *d, int32_t device, rtx_scene *
         rtx_build_hierarchies(pboxes, centre, wide, bvh4, &wstats, pool);
     }
     // k_shadow_coop's level stack (24 levels), queue entry bits, 23-bit prim index of a waiting pair
-    const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 26) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
+    // (and its 32-bit byte offsets into the box lists, 512 B per node, and into the triangle records, 80 B each)
+    const bool wide_ok = 2 * wstats.depth + 2 <= 24 && wstats.nodes < (1 << 23) && d->n_triangles < (1 << 23) && d->n_spheres < (1 << 23);
     // traverse_bvh's stack entries: node index | quantised entry distance (at least 6 bits of it)
     uint32_t bvh4_bits = 1;
     while ((1ll << bvh4_bits) < wstats.nodes4) ++bvh4_bits;
     // (traverse_bvh packs a primitive's index into 24 bits of a pair word)
-    const bool bvh4_ok = bvh4_bits <= 26 && d->n_triangles < (1 << 24) && d->n_spheres < (1 << 24) && std::getenv("RTX_NO_BVH4") == nullptr;
+    const bool bvh4_ok = bvh4_bits <= 25 /* (112-byte nodes at 32-bit byte offsets) */ && d->n_triangles < (1 << 24) && d->n_spheres < (1 << 24) && std::getenv("RTX_NO_BVH4") == nullptr;
     lap(device_build ? "hierarchies (joined device build)" : "hierarchies (SAH, host)");
     if (device_build) {
         ds.wide = dh.wide;

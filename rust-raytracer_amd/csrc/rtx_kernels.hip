@@ -901,7 +901,9 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     float bf = f32_above(best_t - tsh);
     // rows of a DNode4 in 16-byte units: lo.x lo.y lo.z hi.x hi.y hi.z ref
-    const uint32_t onx = r.sx ? 0u : 3u, ofx = r.sx ? 3u : 0u, ony = r.sy ? 1u : 4u, ofy = r.sy ? 4u : 1u, onz = r.sz ? 2u : 5u, ofz = r.sz ? 5u : 2u;
+    // (in BYTES: a node's rows are fetched at 32-bit byte offsets from the array's base, which sits in scalar registers: one 32-bit add per
+    // row instead of a 64-bit one on a per-lane pointer; the host keeps hierarchies that pass 4 GB off these walks)
+    const uint32_t onx = r.sx ? 0u : 48u, ofx = r.sx ? 48u : 0u, ony = r.sy ? 16u : 64u, ofy = r.sy ? 64u : 16u, onz = r.sz ? 32u : 80u, ofz = r.sz ? 80u : 32u;
     // stack entry = node index | quantised entry distance << node_bits; the distance is rounded DOWN (a pop never drops a node that
     // could still hold the closest hit); every entry distance lies in [0, 4 * big]
     const uint32_t nbits = sc.bvh4_node_bits, nmask = (1u << nbits) - 1u;
@@ -932,9 +934,12 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
             }
             have_cur = false;
             WORK(++w_nodes;)
-            const float4 *nq = reinterpret_cast<const float4 *>(sc.bvh4 + cur);
-            const float4 pnx = nq[onx], pny = nq[ony], pnz = nq[onz], pfx = nq[ofx], pfy = nq[ofy], pfz = nq[ofz];
-            const uint4 rf = reinterpret_cast<const uint4 *>(nq)[6];
+            const char *nq = reinterpret_cast<const char *>(sc.bvh4);
+            const uint32_t nb = cur * (uint32_t)sizeof(DNode4);
+            #define BVH4_ROW(off) (*reinterpret_cast<const float4 *>(nq + (nb + (off))))
+            const float4 pnx = BVH4_ROW(onx), pny = BVH4_ROW(ony), pnz = BVH4_ROW(onz), pfx = BVH4_ROW(ofx), pfy = BVH4_ROW(ofy), pfz = BVH4_ROW(ofz);
+            const uint4 rf = *reinterpret_cast<const uint4 *>(nq + (nb + 96u));
+#undef BVH4_ROW
             const float nxs[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, nys[4] = {pny.x, pny.y, pny.z, pny.w}, nzs[4] = {pnz.x, pnz.y, pnz.z, pnz.w};
             const float fxs[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, fys[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, fzs[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
             const uint32_t refs[4] = {rf.x, rf.y, rf.z, rf.w};
@@ -1107,7 +1112,9 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
     const bool finite_dir = fabsf(ix) < 3.0e38f && fabsf(iy) < 3.0e38f && fabsf(iz) < 3.0e38f;
     float bf = f32_above(best_t - tsh);
     // rows of a DNode4 in 16-byte units: lo.x lo.y lo.z hi.x hi.y hi.z ref
-    const uint32_t onx = r.sx ? 0u : 3u, ofx = r.sx ? 3u : 0u, ony = r.sy ? 1u : 4u, ofy = r.sy ? 4u : 1u, onz = r.sz ? 2u : 5u, ofz = r.sz ? 5u : 2u;
+    // (in BYTES: a node's rows are fetched at 32-bit byte offsets from the array's base, which sits in scalar registers: one 32-bit add per
+    // row instead of a 64-bit one on a per-lane pointer; the host keeps hierarchies that pass 4 GB off these walks)
+    const uint32_t onx = r.sx ? 0u : 48u, ofx = r.sx ? 48u : 0u, ony = r.sy ? 16u : 64u, ofy = r.sy ? 64u : 16u, onz = r.sz ? 32u : 80u, ofz = r.sz ? 80u : 32u;
     // stack entry = node index | quantised entry distance << node_bits; the distance is rounded DOWN (a pop never drops a node that
     // could still hold the closest hit); every entry distance lies in [0, 4 * big]
     const uint32_t nbits = sc.bvh4_node_bits, nmask = (1u << nbits) - 1u;
@@ -1310,9 +1317,12 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
             if (visit) {
                 have_cur = false;
                 WORK(++w_nodes;)
-                const float4 *nq = reinterpret_cast<const float4 *>(sc.bvh4 + cur);
-                const float4 pnx = nq[onx], pny = nq[ony], pnz = nq[onz], pfx = nq[ofx], pfy = nq[ofy], pfz = nq[ofz];
-                const uint4 rf = reinterpret_cast<const uint4 *>(nq)[6];
+                const char *nq = reinterpret_cast<const char *>(sc.bvh4);
+                const uint32_t nb = cur * (uint32_t)sizeof(DNode4);
+                #define BVH4_ROW(off) (*reinterpret_cast<const float4 *>(nq + (nb + (off))))
+                const float4 pnx = BVH4_ROW(onx), pny = BVH4_ROW(ony), pnz = BVH4_ROW(onz), pfx = BVH4_ROW(ofx), pfy = BVH4_ROW(ofy), pfz = BVH4_ROW(ofz);
+                const uint4 rf = *reinterpret_cast<const uint4 *>(nq + (nb + 96u));
+#undef BVH4_ROW
                 const float nxs[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, nys[4] = {pny.x, pny.y, pny.z, pny.w}, nzs[4] = {pnz.x, pnz.y, pnz.z, pnz.w};
                 const float fxs[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, fys[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, fzs[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
                 const uint32_t refs[4] = {rf.x, rf.y, rf.z, rf.w};
@@ -2832,7 +2842,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
             uint32_t kind_bit = 0u;
             if ((pr.x & RTX_WREF_KIND) == RTX_WREF_TRI) {
                 int pid, mat;
-                TriV tr = load_tri(sc.tris, (int)idx, &pid, &mat);
+                TriV tr = load_tri(reinterpret_cast<const DTri *>(reinterpret_cast<const char *>(sc.tris) + idx * (uint32_t)sizeof(DTri)), 0, &pid, &mat);   // (idx < 2^23: a 32-bit offset)
                 WORK(++w_prims;)
                 double t, be, ga;
                 occluded = tri_hit(tr, q, EPSILON, q_dist, &t, &be, &ga);
@@ -2897,8 +2907,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
 #endif
         if (g_on) {
             const bool hasB = nodeB != NONE;
-            const float4 *pa = reinterpret_cast<const float4 *>(sc.wide + ((size_t)nodeA * RTX_WIDE + l16));
-            const float4 *pb = reinterpret_cast<const float4 *>(sc.wide + ((size_t)(hasB ? nodeB : nodeA) * RTX_WIDE + l16));
+            // (32-bit byte offsets from the array's base, which sits in scalar registers: one add per record instead of a 64-bit shift and
+            // add on a per-lane pointer that the allocator kept in scratch; the host keeps scenes whose box lists pass 4 GB off this kernel)
+            const char *wbytes = reinterpret_cast<const char *>(sc.wide);
+            const uint32_t l16off = l16 * (uint32_t)sizeof(DWideChild);
+            const float4 *pa = reinterpret_cast<const float4 *>(wbytes + (nodeA * (uint32_t)(RTX_WIDE * sizeof(DWideChild)) + l16off));
+            const float4 *pb = reinterpret_cast<const float4 *>(wbytes + ((hasB ? nodeB : nodeA) * (uint32_t)(RTX_WIDE * sizeof(DWideChild)) + l16off));
             const float4 a_lo = pa[0], a_hi = pa[1], b_lo = pb[0], b_hi = pb[1];
             WORK(w_nodes += hasB ? 2u : 1u;)
             const uint32_t refA = __float_as_uint(a_hi.z), refB = __float_as_uint(b_hi.z);
@@ -2980,7 +2994,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
                             const float4 ra = s_rayf[0][ot], rn = s_rayf[1][ot];
                             const float2 rg = s_rayg[ot];
                             const float4 rf = make_float4(rn.w, rg.x, rg.y, 0.0f);
-                            const float4 *pc = reinterpret_cast<const float4 *>(sc.wide + (size_t)c);   // c = node * 16 + slot
+                            const float4 *pc = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.wide) + c * (uint32_t)sizeof(DWideChild));   // c = node * 16 + slot
                             const float4 c_lo = pc[0], c_hi = pc[1];
                             const float lx = c_lo.x, ly = c_lo.y, lz = c_lo.z, ux = c_lo.w, uy = c_hi.x, uz = c_hi.y;
                             WORK(++w_entries;)

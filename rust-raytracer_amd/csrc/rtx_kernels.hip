@@ -182,6 +182,10 @@ DEV TriV load_tri(const DTri *tris, int idx, int *prim_id, int *material) {
     *material = (int)(ids >> 32);
     return t;
 }
+// the same at a 32-bit byte offset from the array's base (the walks over the SAH hierarchies: the host keeps scenes of 2^24 triangles and more off them)
+DEV TriV load_tri32(const DTri *tris, uint32_t idx, int *prim_id, int *material) {
+    return load_tri(reinterpret_cast<const DTri *>(reinterpret_cast<const char *>(tris) + idx * (uint32_t)sizeof(DTri)), 0, prim_id, material);
+}
 // Triangle::intersects up to t, geometry/prims/triangle.rs:111-133 (Möller–Trumbore, two-sided)
 DEV bool tri_hit(const TriV &tr, const Ray &r, double t_min, double t_max, double *t_out, double *beta_out,
                  double *gamma_out) {
@@ -1003,7 +1007,7 @@ DEV void traverse_bvh(const DScene &sc, const Ray &r, bool active, uint32_t *s_s
                     const bool surely_in = (c & 1u) != 0u;
                     if (ref >= 0) {
                         int pid, mat;
-                        TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                        TriV tr = load_tri32(sc.tris, (uint32_t)ref, &pid, &mat);
                         if (surely_in || tri_bbox_hit(tr, r)) {
                             WORK(++w_prims;)
                             double t, be, ga;
@@ -1239,7 +1243,7 @@ DEV void traverse_bvh_dealt(const DScene &sc, const Ray &r, bool active, uint32_
         if (run) {
             if (ref >= 0) {
                 int pid, mat;
-                TriV tr = load_tri(sc.tris, ref, &pid, &mat);
+                TriV tr = load_tri32(sc.tris, (uint32_t)ref, &pid, &mat);
                 if (surely_in || tri_bbox_hit(tr, q)) {
                     WORK(++w_prims;)
                     double be, ga;
@@ -2842,7 +2846,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MULTI ? RTX_COOP_WAVES_MULTI : RTX_
             uint32_t kind_bit = 0u;
             if ((pr.x & RTX_WREF_KIND) == RTX_WREF_TRI) {
                 int pid, mat;
-                TriV tr = load_tri(reinterpret_cast<const DTri *>(reinterpret_cast<const char *>(sc.tris) + idx * (uint32_t)sizeof(DTri)), 0, &pid, &mat);   // (idx < 2^23: a 32-bit offset)
+                TriV tr = load_tri32(sc.tris, idx, &pid, &mat);   // (idx < 2^23)
                 WORK(++w_prims;)
                 double t, be, ga;
                 occluded = tri_hit(tr, q, EPSILON, q_dist, &t, &be, &ga);

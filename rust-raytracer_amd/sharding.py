@@ -38,9 +38,11 @@ class StillGather:
     RTX_FLAG_COMPACT_OUTPUT: its own blocks, packed.  gather(dist) sends it as it is; gather(dist, rgba=full_frame)
     packs the rank's blocks out of a full-size frame first (callers that rendered without the flag)."""
 
-    def __init__(self, width, height, rank, world, device):
+    def __init__(self, width, height, rank, world, device, always_collective=False):
         assert height % 8 == 0, "image_height must be a multiple of 8 (renderer.rs:73)"
         self.W, self.H, self.rank, self.world = width, height, rank, world
+        # always_collective: issue the gather on a group of ONE rank too (a one-GPU rehearsal of the RCCL calls, tools/gpu_rccl_rehearsal.py)
+        self.collective = world > 1 or always_collective
         self.n_blocks = height // 8
         self.row_bytes = 8 * width * 4
         self.mine = blocks_of_rank(height, rank, world)
@@ -56,7 +58,7 @@ class StillGather:
             self.dst = torch.tensor(dst, dtype=torch.long, device=device)
             self._padded = torch.zeros((self.n_blocks + 1, self.row_bytes), dtype=torch.uint8, device=device)
             self.final = self._padded[:self.n_blocks].view(height, width, 4)
-            self.compact = self.recv[0] if world == 1 else torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
+            self.compact = self.recv[0] if not self.collective else torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
         else:
             self.compact = torch.zeros((self.max_blocks, self.row_bytes), dtype=torch.uint8, device=device)
         self.target = self.compact.view(self.max_blocks * 8, width, 4)
@@ -65,7 +67,7 @@ class StillGather:
         """Returns the assembled frame on rank 0, None elsewhere."""
         if rgba is not None and self.mine:
             self.compact[:len(self.mine)] = rgba.view(self.n_blocks, self.row_bytes).index_select(0, self.idx)
-        if self.world > 1:
+        if self.collective:
             dist.gather(self.compact, self.parts, dst=0)
             if self.rank != 0:
                 return None
@@ -84,12 +86,13 @@ class FrameGather:
 
     TRAILER = 16
 
-    def __init__(self, height, width, rank, world, device, dist):
+    def __init__(self, height, width, rank, world, device, dist, always_collective=False):
         self.H, self.W, self.rank, self.world, self.dist = height, width, rank, world, dist
+        self.collective = world > 1 or always_collective   # (as StillGather)
         self.nbytes = height * width * 4
         self.send = [torch.zeros(self.nbytes + self.TRAILER, dtype=torch.uint8, device=device) for _ in range(2)]
         self.recv = ([[torch.zeros_like(self.send[0]) for _ in range(world)] for _ in range(2)]
-                     if (world > 1 and rank == 0) else None)
+                     if (self.collective and rank == 0) else None)
         self.round = 0
         self.pending = None      # (work handle or None, buffer index)
 
@@ -102,7 +105,7 @@ class FrameGather:
             work.wait()
         if self.rank != 0:
             return None
-        bufs = self.recv[b] if self.world > 1 else [self.send[b]]
+        bufs = self.recv[b] if self.collective else [self.send[b]]
         # one host read for the round's flags (the frames stay where they are)
         flags = torch.stack([p[self.nbytes] for p in bufs]).cpu().tolist()
         return [p[:self.nbytes].view(self.H, self.W, 4) if f else None for p, f in zip(bufs, flags)]
@@ -115,7 +118,7 @@ class FrameGather:
             buf[:self.nbytes].copy_(frame.reshape(-1))
         buf[self.nbytes:].fill_(1 if frame is not None else 0)
         work = None
-        if self.world > 1:
+        if self.collective:
             work = self.dist.gather(buf, self.recv[b] if self.rank == 0 else None, dst=0, async_op=True)
         self.pending = (work, b)
         self.round += 1
@@ -145,7 +148,7 @@ def frame_name(output_file, starting_frame_number, frame_number):
     return "%s%06d.ppm" % (output_file, starting_frame_number + frame_number)
 
 
-def animate(frames, rank, world, dist, render_frame, on_frame=None, shape=None, device=None):
+def animate(frames, rank, world, dist, render_frame, on_frame=None, shape=None, device=None, always_collective=False):
     """N-rank animation driver: frame k of `frames` (a list of (frame_number, time)) is rendered by rank k % world with
     render_frame(frame_number, time) -> [H, W, 4] uint8 tensor; ONE gather per round of `world` frames brings the round's frames
     to rank 0, overlapped with the next round's rendering (FrameGather), and rank 0 hands them to
@@ -179,7 +182,7 @@ def animate(frames, rank, world, dist, render_frame, on_frame=None, shape=None, 
                 first = (frame.shape[0], frame.shape[1], frame.device)
             else:
                 first = (shape[0], shape[1], device if device is not None else torch.device("cpu"))
-            fg = FrameGather(first[0], first[1], rank, world, first[2], dist)
+            fg = FrameGather(first[0], first[1], rank, world, first[2], dist, always_collective)
         done = fg.submit(frame)          # starts this round's gather; completes the previous round's
         deliver(prev_base, done)
         prev_base = base

@@ -396,6 +396,8 @@ struct Work {
     DShadowQ sq{};
     DShadowQ sq2{};           // second shadow queue: the shadow launches of one step overlap the next step's closest-hit launch
     hipStream_t aux[2] = {nullptr, nullptr};   // the streams the shadow launches run on when they overlap (lights alternate)
+    RtxSortBuf sortbuf{};     // the sort of a step's shadow groups by cell (rtx_sort.hip); the queues hold their own cell / order arrays
+    uint32_t sort_cap = 0;
     DCounters *d_counters = nullptr;
     DCounters *h_up = nullptr, *h_back = nullptr;   // pinned
     unsigned long long (*d_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr;
@@ -551,6 +553,12 @@ void free_work(Work &w) {
     if (w.sq.count) hipFree(w.sq.count);
     if (w.sq.res) hipFree(w.sq.res);
     if (w.sq.sample0) hipFree(w.sq.sample0);
+    if (w.sq.cell) hipFree(w.sq.cell);
+    if (w.sq.order) hipFree(w.sq.order);
+    if (w.sq2.cell) hipFree(w.sq2.cell);
+    if (w.sq2.order) hipFree(w.sq2.order);
+    if (w.sortbuf.cell_sorted) hipFree(w.sortbuf.cell_sorted);
+    if (w.sortbuf.tmp) hipFree(w.sortbuf.tmp);
     if (w.sq2.f) hipFree(w.sq2.f);
     if (w.sq2.key) hipFree(w.sq2.key);
     if (w.sq2.sample) hipFree(w.sq2.sample);
@@ -589,7 +597,7 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
     }
     size_t nl = std::max<size_t>(s->lights.size(), 1);
     if (w.sq.cap < batch) {
-        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); hipFree(w.sq.wide); hipFree(w.sq.res); hipFree(w.sq.sample0); uint32_t *keep = w.sq.retry, *keep2 = w.sq.count; w.sq = DShadowQ(); w.sq.retry = keep; w.sq.count = keep2; }
+        if (w.sq.f) { hipFree(w.sq.f); hipFree(w.sq.key); hipFree(w.sq.sample); hipFree(w.sq.wide); hipFree(w.sq.res); hipFree(w.sq.sample0); hipFree(w.sq.cell); hipFree(w.sq.order); uint32_t *keep = w.sq.retry, *keep2 = w.sq.count; w.sq = DShadowQ(); w.sq.retry = keep; w.sq.count = keep2; }
         w.sq.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq.f, nl * 6 * (size_t)batch))) return st;
@@ -598,12 +606,13 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         if ((st = dev_alloc(&w.sq.wide, nl * (1u + (size_t)batch)))) return st;
         if ((st = dev_alloc(&w.sq.res, nl * 3 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq.sample0, (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq.cell, (size_t)batch)) || (st = dev_alloc(&w.sq.order, 1u + (size_t)batch))) return st;
         if (!w.sq.retry && (st = dev_alloc(&w.sq.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         if (!w.sq.count && (st = dev_alloc(&w.sq.count, 16))) return st;
         w.sq.cap = batch;
     }
     if (w.sq2.cap < batch) {
-        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); hipFree(w.sq2.wide); hipFree(w.sq2.res); hipFree(w.sq2.sample0); uint32_t *keep = w.sq2.retry, *keep2 = w.sq2.count; w.sq2 = DShadowQ(); w.sq2.retry = keep; w.sq2.count = keep2; }
+        if (w.sq2.f) { hipFree(w.sq2.f); hipFree(w.sq2.key); hipFree(w.sq2.sample); hipFree(w.sq2.wide); hipFree(w.sq2.res); hipFree(w.sq2.sample0); hipFree(w.sq2.cell); hipFree(w.sq2.order); uint32_t *keep = w.sq2.retry, *keep2 = w.sq2.count; w.sq2 = DShadowQ(); w.sq2.retry = keep; w.sq2.count = keep2; }
         w.sq2.retry_cap = RTX_RETRY_CAP;
         rtx_status st;
         if ((st = dev_alloc(&w.sq2.f, nl * 6 * (size_t)batch))) return st;
@@ -612,9 +621,18 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         if ((st = dev_alloc(&w.sq2.wide, nl * (1u + (size_t)batch)))) return st;
         if ((st = dev_alloc(&w.sq2.res, nl * 3 * (size_t)batch))) return st;
         if ((st = dev_alloc(&w.sq2.sample0, (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sq2.cell, (size_t)batch)) || (st = dev_alloc(&w.sq2.order, 1u + (size_t)batch))) return st;
         if (!w.sq2.retry && (st = dev_alloc(&w.sq2.retry, nl * (2u + 2u * RTX_RETRY_CAP)))) return st;
         if (!w.sq2.count && (st = dev_alloc(&w.sq2.count, 16))) return st;
         w.sq2.cap = batch;
+    }
+    if (w.sort_cap < batch) {
+        if (w.sortbuf.cell_sorted) { hipFree(w.sortbuf.cell_sorted); hipFree(w.sortbuf.tmp); w.sortbuf = RtxSortBuf(); w.sort_cap = 0; }
+        rtx_status st;
+        if ((st = dev_alloc(&w.sortbuf.cell_sorted, (size_t)batch))) return st;
+        w.sortbuf.tmp_bytes = rtxk_sort_temp_bytes(batch);
+        HIPCHECK(hipMalloc(&w.sortbuf.tmp, std::max<size_t>(w.sortbuf.tmp_bytes, 256)));
+        w.sort_cap = batch;
     }
     for (hipStream_t &a : w.aux)
         if (!a) HIPCHECK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
@@ -908,6 +926,23 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     for (const rtx_light &lt : s->lights) n_soft += lt.kind != RTX_LIGHT_POINT ? 1u : 0u;
     const bool direct_acc = std::getenv("RTX_DIRECT_ACC") != nullptr ||
                             (!(n_soft >= 2u && opt->shadow_samples >= 16u) && std::getenv("RTX_DEFER_ACC") == nullptr);
+    // Sorted shadow launches (rtx_sort.hip): the steps of the second generation and later whose feelers run in a per-lane kernel (no
+    // cooperative walk for that light's try count) and that are large enough to fill the chip many times over.  Measured heptoroid
+    // (480x272, depth 10/10): k_shadow<7> 216.7 -> see DESIGN section 11.  RTX_NO_SORT=1 / RTX_SORT_ALL=1 (every step, primaries too): A/B.
+    bool per_lane_shadows = false;
+    {
+        const bool coop_scene = s->d.all_opaque && s->d.wide && !(fr.flags & (RTX_FLAG_NO_COOP | RTX_FLAG_INTERNAL_EXACT_SHADOWS));
+        for (const rtx_light &lt : s->lights) {
+            const uint32_t tries = lt.kind == RTX_LIGHT_POINT ? 1u : opt->shadow_samples;
+            if (!(coop_scene && (tries % 16u == 0u || tries == 4u || tries == 8u))) per_lane_shadows = true;
+        }
+    }
+    const bool sort_all = std::getenv("RTX_SORT_ALL") != nullptr;
+    const bool sort_steps = !noalloc && opt->shadow_samples > 0 && per_lane_shadows && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) &&
+                            (!s->d.all_opaque || std::getenv("RTX_SORT_OPAQUE") != nullptr) && std::getenv("RTX_NO_SORT") == nullptr;
+    uint32_t sort_min = 1u << 16, sort_gen = 1u;
+    if (const char *e = std::getenv("RTX_SORT_MIN")) sort_min = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("RTX_SORT_GEN")) sort_gen = (uint32_t)std::atoi(e);
     bool coop_defer_ran = false;
     // k_shade's small instance (96 VGPRs, spills) for frames whose shadow feelers run in k_shadow_coop<false> beside the next step's closest-hit /
     // shade launches: it paid while every workgroup of k_shade waited for a returning atomic on the pool's tail (sponza 208.6 -> 204.6 ms);
@@ -957,8 +992,11 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         }
         DShadowQ sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
         if (direct_acc) sq.res = nullptr;   // A/B: every shadow launch adds its results to the samples itself
+        const bool sort_step = sort_steps && (sort_all || (top_gen >= sort_gen && n >= sort_min));
+        if (!sort_step) sq.cell = sq.order = nullptr;
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
-                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace);
+                   overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace,
+                   sort_step ? &w.sortbuf : nullptr);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));

@@ -192,6 +192,11 @@ struct DShadowQ {
     uint32_t *sample0;  // [cap]: the group's primary sample once more (k_shadow_coop<MULTI> marks the per-light copies it is done with)
     uint32_t *count;    // one word: the groups of the step (the same for every light: a ray that hits emits one per light)
     uint32_t *wide;     // [n_lights][1 + cap]: count, then the queue groups k_shadow_coop<MULTI> leaves to the per-lane kernel that follows it
+    // Sorted launches (per-lane shadow kernels on rays of the second generation and later, whose hit points lie all over the scene):
+    // k_shade writes the cell of the group's hit point (24-bit Morton code in the scene's cube), rtxk_sort_groups orders the groups by
+    // it, and the light's launch takes its groups through `order`: neighbouring lanes walk neighbouring feelers.  NULL: queue order.
+    uint32_t *cell;     // [cap]
+    uint32_t *order;    // [1 + cap]: count, then the queue's groups by cell
     uint32_t cap;
     uint32_t retry_cap; // pairs per light (RTX_RETRY_CAP in the library's own workspace, smaller in the static one)
 };
@@ -235,13 +240,19 @@ typedef void *rtx_stream_t;
 void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count);
 // (names: what was launched, as rocprofv3 prints it, e.g. "k_closest<5>": rtx_last_kernel_names, for the measurement harness)
 struct RtxTraceNames { const char *closest = ""; const char *shade = ""; };
+// what the sort of a step's shadow groups needs beside the queue's own arrays (shared by the two queues: the sorts run one after the
+// other on the main stream)
+struct RtxSortBuf { uint32_t *cell_sorted = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0; };
+size_t rtxk_sort_temp_bytes(uint32_t n);
+// orders the groups [0, n) of the queue by sq.cell (slots past *sq.count hold ~0 and come last) into sq.order; rtx_sort.hip
+void rtxk_sort_groups(rtx_stream_t stream, const DShadowQ &sq, const RtxSortBuf &sb, uint32_t n);
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */,
                 void *record_after_closest /* hipEvent_t or NULL: recorded between the closest-hit launches and the shading launches (timing) */,
                 uint32_t *group_base /* [4 * ceil(count / RTX_BLOCK)]: rays that hit something per workgroup, their exclusive scan; children per workgroup, their scan */,
                 uint32_t child_begin /* the pool's tail before the step: where its children go */,
-                RtxTraceNames *names = nullptr);
+                RtxTraceNames *names = nullptr, const RtxSortBuf *sortbuf = nullptr /* with sq.cell and sq.order: the step's groups are sorted */);
 // returns the name of the kernel that does the launch's work ("" when nothing was launched)
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc,

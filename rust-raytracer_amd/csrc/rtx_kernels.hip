@@ -2006,6 +2006,21 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_
 // slower alone (spills: bunny 5.98 -> 7.6 ms if it were used there), so it runs only where the shadow kernel dominates: sponza frame 208.6 ->
 // 204.6 ms.  Compiled without the f64 pow / acos / sin / cos of Ray::perturb (glossy reflection) and of the Phong term, which would spill far
 // more: scenes that need them (DScene.shade_features != 0) always take the general instance.
+// the cell of a hit point in the scene's cube, 8 bits per axis, bits interleaved (Morton order): the sort key of its shadow groups
+// (DShadowQ.cell).  Points outside the cube (planes that run to the horizon) clamp to its faces.
+DEV uint32_t spread8(uint32_t x) {
+    x = (x | (x << 8)) & 0x00F00Fu;
+    x = (x | (x << 4)) & 0x0C30C3u;
+    x = (x | (x << 2)) & 0x249249u;
+    return x;
+}
+DEV uint32_t hit_cell(const DScene &sc, V3 p) {
+    const float s = 128.0f / (float)sc.radius;
+    const float fx = fminf(fmaxf(((float)(p.x - sc.centre[0])) * s + 128.0f, 0.0f), 255.0f);
+    const float fy = fminf(fmaxf(((float)(p.y - sc.centre[1])) * s + 128.0f, 0.0f), 255.0f);
+    const float fz = fminf(fmaxf(((float)(p.z - sc.centre[2])) * s + 128.0f, 0.0f), 255.0f);
+    return spread8((uint32_t)fx) | (spread8((uint32_t)fy) << 1) | (spread8((uint32_t)fz) << 2);
+}
 template <bool GENERAL>
 __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHADE_WAVES_LEAN) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                      const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
@@ -2169,6 +2184,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
             size_t qc = sq.cap;
             sq.sample[(size_t)li * qc + gslot] = sample;
             if (li == 0 && sq.sample0) sq.sample0[gslot] = sample;
+            if (li == 0 && sq.cell) sq.cell[gslot] = hit_cell(sc, hp);
             double *f = sq.f + (size_t)li * 6 * qc + gslot;
             f[0 * qc] = hp.x; f[1 * qc] = hp.y; f[2 * qc] = hp.z;
             f[3 * qc] = w.x; f[4 * qc] = w.y; f[5 * qc] = w.z;
@@ -3333,7 +3349,7 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, uint32_t child_begin,
-                RtxTraceNames *names) {
+                RtxTraceNames *names, const RtxSortBuf *sortbuf) {
     if (count == 0) return;
     RtxTraceNames nm;
     static_assert(MODE_CLOSEST == 0 && MODE_CLOSEST_REF == 1 && MODE_CLOSEST_BVH == 5 && MODE_CLOSEST_BVH_DEALT == 8, "the kernel names below");
@@ -3372,12 +3388,16 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     // (after the waits: it writes the queue's group count) also moves the pool's tail past the step's children
     hipLaunchKernelGGL(k_group_base, dim3(grid_for(nb)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, hit_count, child_count, nb, hit_base, child_base,
                        sq.count, child_begin, pool.cap, counters);
+    const bool sorted = want_groups && sortbuf && sq.cell && sq.order;
+    if (!sorted) sq.cell = nullptr;
+    if (sorted) (void)hipMemsetAsync(sq.cell, 0xFF, (size_t)count * sizeof(uint32_t), (hipStream_t)stream);   // (slots past the queue's count sort last)
     if (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE))
         hipLaunchKernelGGL(k_shade<true>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
                            hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin);
     else
         hipLaunchKernelGGL(k_shade<false>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
                            hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin);
+    if (sorted) rtxk_sort_groups(stream, sq, *sortbuf, count);
 }
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                         uint32_t tries, DCounters *counters, double *acc, bool coop_defer) {
@@ -3442,19 +3462,19 @@ const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr,
                                n_groups, tries, pow2, counters, acc, sq.wide + (size_t)light * (1u + (size_t)sq.cap));
     } else if (sc.all_opaque && bvh)
         hipLaunchKernelGGL(k_shadow<MODE_ANY_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc, nullptr);
+                           n_groups, tries, pow2, counters, acc, sq.order);
     else if (sc.all_opaque)
         hipLaunchKernelGGL(k_shadow<MODE_ANY>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc, nullptr);
+                           n_groups, tries, pow2, counters, acc, sq.order);
     else if (fr.flags & RTX_FLAG_REFERENCE_ORDER)   // all-f64 restatement of the reference's walk
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc, nullptr);
+                           n_groups, tries, pow2, counters, acc, sq.order);
     else if (product_bvh)   // the distinct hit prims over the 4-wide hierarchy, then their multiplicities
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_BVH>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc, nullptr);
+                           n_groups, tries, pow2, counters, acc, sq.order);
     else
         hipLaunchKernelGGL(k_shadow<MODE_PRODUCT_FAST>, dim3(grid_for(lanes)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light,
-                           n_groups, tries, pow2, counters, acc, nullptr);
+                           n_groups, tries, pow2, counters, acc, sq.order);
     if (any_hit)
         hipLaunchKernelGGL(k_shadow_retry, dim3(64), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, sq, light, tries, acc);
     return name;

@@ -233,3 +233,40 @@ def test_deferred_accumulation_equals_direct(rtx, orc, which, tries, monkeypatch
         assert (np.abs(x[..., :3].astype(int) - o[..., :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
     assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3
     assert (np.abs(a.astype(int) - a2.astype(int)) <= 1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mesh", "mesh_transmissive", "kitchen"])
+@pytest.mark.parametrize("tries", [1, 3, 4, 16])
+def test_sorted_shadow_launches_equal_queue_order(rtx, orc, which, tries, monkeypatch):
+    """The per-lane shadow launches of later generations take their groups in the order of the hit points' cells (DShadowQ.cell /
+    order, rtx_sort.hip) in scenes with transmissive materials; RTX_SORT_ALL + RTX_SORT_OPAQUE force the sort for every step of
+    every scene, RTX_NO_SORT switches it off.  The order of a launch's lanes changes nothing but the order of f64 additions:
+    same ids, same ray counts, images within one 8-bit step of each other and of the oracle.  Small batches (many steps, both
+    queues in turn; slots past a step's count hold stale cells), overlapped and serial; 3 tries: groups that span waves."""
+    if which == "kitchen":
+        flat, cam_fn = scenes.kitchen_sink_scene(rtx)
+    else:
+        flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=(which == "mesh_transmissive"))
+    cam = cam_fn(160, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=4, refract_depth=4, shadow_samples=tries, pixel_samples=2, rng_mode=1, seed=5, batch_rays=8192)
+    no_coop = rtx.abi.FLAG_NO_COOP    # (opaque scenes with 4 or 16 tries: per-lane kernels instead of the cooperative ones)
+    monkeypatch.setenv("RTX_SORT_MIN", "0")     # (the default leaves steps of fewer than 65 536 rays alone)
+    monkeypatch.setenv("RTX_SORT_ALL", "1")
+    monkeypatch.setenv("RTX_SORT_OPAQUE", "1")
+    a, ia, sa = sc.render(cam, rtx.options(flags=no_coop, **kw))
+    a2, ia2, sa2 = sc.render(cam, rtx.options(flags=no_coop | rtx.abi.FLAG_SERIAL, **kw))
+    monkeypatch.delenv("RTX_SORT_ALL")
+    monkeypatch.delenv("RTX_SORT_OPAQUE")
+    d, id_, sd = sc.render(cam, rtx.options(flags=no_coop, **kw))          # the default: later generations of transmissive scenes
+    monkeypatch.setenv("RTX_NO_SORT", "1")
+    b, ib, sb = sc.render(cam, rtx.options(flags=no_coop, **kw))
+    monkeypatch.delenv("RTX_NO_SORT")
+    sc.close()
+    o, io, so = orc.Scene(flat).render(cam, rtx.options(**kw), threads=16)
+    for x, ix, sx in ((a, ia, sa), (a2, ia2, sa2), (d, id_, sd), (b, ib, sb)):
+        assert np.array_equal(ix, io) and sx.rays_total == so.rays_total
+        assert (np.abs(x[..., :3].astype(int) - o[..., :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3
+    assert (np.abs(a2.astype(int) - b.astype(int)) <= 1).all() and (np.abs(d.astype(int) - b.astype(int)) <= 1).all()

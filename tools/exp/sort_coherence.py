@@ -36,6 +36,10 @@ def main():
     scene = pkg.Scene(named, device=0)
     light = np.array(list(named.lights[0].position), dtype=np.float64)
     rng = np.random.default_rng(1)
+    physical = os.environ.get("PHYSICAL", "1") == "1"
+    nt = int(named.desc.n_triangles)
+    verts = np.ctypeslib.as_array(named.desc.tri_vertices, shape=(nt, 3, 3)).copy()
+    assert int(named.desc.n_prims) == nt, "the experiment takes prim ids for triangle indices"
     W, H = (int(x) for x in os.environ.get("GRID", "480x272").split("x"))
     cam = named.camera(W, H, 45.0)
     eye = np.array(list(cam.position), dtype=np.float64) if hasattr(cam, "position") else None
@@ -64,6 +68,7 @@ def main():
             keys = {"random": rng.permutation(len(o)), "origin30": np.argsort(m30, kind="stable"),
                     "origin30_then_octant": np.argsort(m30 * 8 + octant, kind="stable"),
                     "octant_then_origin30": np.argsort((octant << 30) | m30, kind="stable"),
+                    "octant_then_origin21": np.argsort((octant << 21) | (m30 >> 9), kind="stable"),
                     "origin18": np.argsort(m30 >> 12, kind="stable"),
                     "origin18_then_octant": np.argsort((m30 >> 12) * 8 + octant, kind="stable")}
             for name, perm in keys.items():
@@ -71,9 +76,23 @@ def main():
                 ok = bool(np.array_equal(pid2, pid[perm]) and np.array_equal(tt2, tt[perm]))
                 print("nearest order %s: same hits %s" % (name, ok), flush=True)
             break
-        n = unit(rng.normal(size=hp.shape))
-        refl = dh - 2.0 * np.sum(dh * n, axis=1, keepdims=True) * n
-        straight = unit(dh + 0.15 * rng.normal(size=hp.shape))
+        if physical:
+            # the scene's own mirror and transmission directions (flat normals of the triangles hit, ior 1.5, total internal
+            # reflection -> the mirror direction, as renderer.rs:148-186): the ray tree of the frame, two children per hit
+            tri = verts[pid[hit]]
+            n = unit(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]))
+            cosi = np.sum(dh * n, axis=1, keepdims=True)
+            nf = np.where(cosi < 0, n, -n)
+            c = -np.sum(dh * nf, axis=1, keepdims=True)
+            refl = dh + 2.0 * c * nf
+            eta = np.where(cosi < 0, 1.0 / 1.5, 1.5)
+            k = 1.0 - eta * eta * (1.0 - c * c)
+            straight = np.where(k < 0, refl, eta * dh + (eta * c - np.sqrt(np.maximum(k, 0.0))) * nf)
+            straight = unit(straight)
+        else:
+            n = unit(rng.normal(size=hp.shape))
+            refl = dh - 2.0 * np.sum(dh * n, axis=1, keepdims=True) * n
+            straight = unit(dh + 0.15 * rng.normal(size=hp.shape))
         o = np.repeat(hp, 2, axis=0)
         d = np.empty_like(o)
         d[0::2] = refl

@@ -541,10 +541,11 @@ private:
 };
 
 void free_work(Work &w) {
-    if (w.pool.f) hipFree(w.pool.f);
-    if (w.pool.key) hipFree(w.pool.key);
-    if (w.pool.sample) hipFree(w.pool.sample);
+    if (w.pool.rec) hipFree(w.pool.rec);
+    if (w.pool.thr) hipFree(w.pool.thr);
     if (w.pool.flags) hipFree(w.pool.flags);
+    if (w.pool.cell) hipFree(w.pool.cell);
+    if (w.sortbuf.ray_order) hipFree(w.sortbuf.ray_order);
     if (w.sq.f) hipFree(w.sq.f);
     if (w.sq.key) hipFree(w.sq.key);
     if (w.sq.sample) hipFree(w.sq.sample);
@@ -587,12 +588,12 @@ void free_work(Work &w) {
 rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n_samples) {
     Work &w = s->w;
     if (w.pool.cap < pool_cap) {
-        if (w.pool.f) { hipFree(w.pool.f); hipFree(w.pool.key); hipFree(w.pool.sample); hipFree(w.pool.flags); w.pool = DPool(); }
+        if (w.pool.rec) { hipFree(w.pool.rec); hipFree(w.pool.thr); hipFree(w.pool.flags); hipFree(w.pool.cell); w.pool = DPool(); }
         rtx_status st;
-        if ((st = dev_alloc(&w.pool.f, (size_t)pool_cap * 9))) return st;
-        if ((st = dev_alloc(&w.pool.key, pool_cap))) return st;
-        if ((st = dev_alloc(&w.pool.sample, pool_cap))) return st;
+        if ((st = dev_alloc(&w.pool.rec, (size_t)pool_cap))) return st;
+        if ((st = dev_alloc(&w.pool.thr, (size_t)pool_cap * 3))) return st;
         if ((st = dev_alloc(&w.pool.flags, pool_cap))) return st;
+        if ((st = dev_alloc(&w.pool.cell, pool_cap))) return st;
         w.pool.cap = pool_cap;
     }
     size_t nl = std::max<size_t>(s->lights.size(), 1);
@@ -627,9 +628,9 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         w.sq2.cap = batch;
     }
     if (w.sort_cap < batch) {
-        if (w.sortbuf.cell_sorted) { hipFree(w.sortbuf.cell_sorted); hipFree(w.sortbuf.tmp); w.sortbuf = RtxSortBuf(); w.sort_cap = 0; }
+        if (w.sortbuf.cell_sorted) { hipFree(w.sortbuf.cell_sorted); hipFree(w.sortbuf.tmp); hipFree(w.sortbuf.ray_order); w.sortbuf = RtxSortBuf(); w.sort_cap = 0; }
         rtx_status st;
-        if ((st = dev_alloc(&w.sortbuf.cell_sorted, (size_t)batch))) return st;
+        if ((st = dev_alloc(&w.sortbuf.cell_sorted, (size_t)batch)) || (st = dev_alloc(&w.sortbuf.ray_order, (size_t)batch))) return st;
         w.sortbuf.tmp_bytes = rtxk_sort_temp_bytes(batch);
         HIPCHECK(hipMalloc(&w.sortbuf.tmp, std::max<size_t>(w.sortbuf.tmp_bytes, 256)));
         w.sort_cap = batch;
@@ -718,10 +719,10 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t fixed = up(sizeof(DCounters)) + up(RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)) +
                          up((size_t)std::max<uint32_t>(n_samples, 1) * 3 * sizeof(double)) + 23 * 256 /* alignment of the arrays below */;
-    // per ray of a batch: hit record 12 (+ 16 per workgroup for the queue and pool slots), pool (per_batch rays of 88 B), one shadow queue entry per light 60, one retry pair per light 8,
+    // per ray of a batch: hit record 12 (+ 16 per workgroup for the queue and pool slots), pool (per_batch rays of 92 B), one shadow queue entry per light 60, one retry pair per light 8,
     // one entry per light in the list of groups left to the per-lane shadow kernel 4
     const size_t pool_per = std::max<uint64_t>(need.per_batch, 1 + (uint64_t)need.fanout);
-    const size_t per = 12 + 1 + pool_per * 88 + nl * 60 + nl * 8 + nl * 4 + nl * 24 + 4;   // (+ the lights' deferred results and the clean sample plane)
+    const size_t per = 12 + 1 + pool_per * 92 + nl * 60 + nl * 8 + nl * 4 + nl * 24 + 4;   // (+ the lights' deferred results and the clean sample plane)
     if (fixed + per * RTX_BLOCK + nl * 8 + nl * 256 > RTX_STATIC_SCRATCH_BYTES)
         return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: this call needs " + std::to_string(fixed + per * RTX_BLOCK) +
                                        " bytes of workspace, the static device scratch holds " + std::to_string(RTX_STATIC_SCRATCH_BYTES) +
@@ -738,9 +739,8 @@ rtx_status carve_static(uint8_t *base, size_t n_lights, uint32_t n_samples, cons
     v.hit_t = (double *)take(batch * sizeof(double));
     v.hit_ref = (int32_t *)take(batch * sizeof(int32_t));
     v.group_base = (uint32_t *)take(4 * (batch / RTX_BLOCK + 2) * sizeof(uint32_t));
-    v.pool.f = (double *)take(pool_cap * 9 * sizeof(double));
-    v.pool.key = (uint64_t *)take(pool_cap * sizeof(uint64_t));
-    v.pool.sample = (uint32_t *)take(pool_cap * sizeof(uint32_t));
+    v.pool.rec = (DRayRec *)take(pool_cap * sizeof(DRayRec));
+    v.pool.thr = (double *)take(pool_cap * 3 * sizeof(double));
     v.pool.flags = (uint32_t *)take(pool_cap * sizeof(uint32_t));
     v.pool.cap = (uint32_t)pool_cap;
     v.sq.f = (double *)take(nl * 6 * batch * sizeof(double));
@@ -820,11 +820,11 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if ((st = carve_static(base, s->lights.size(), n_samples, need, opt->batch_rays, v, &batch, &pool_cap))) return st;
     } else {
         if (!batch) {   // default: 8 Mi rays per launch (measured: bunny 10.9 -> 9.9 ms against 4 Mi, sponza within 1 %; heptoroid depth 10:
-                        // 664 -> 632 ms against 1.8 Mi), shrunk so that the pool (88 B per ray) stays within a quarter of the device memory
+                        // 664 -> 632 ms against 1.8 Mi), shrunk so that the pool (92 B per ray) stays within a quarter of the device memory
                         // that is free now (the pool this handle already holds counts as free) and never below 64 Mi rays (5.6 GB)
             size_t free_b = 0, total_b = 0;
             HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-            const uint64_t room = ((uint64_t)free_b + (uint64_t)w.pool.cap * 88u) / 4u / 88u;
+            const uint64_t room = ((uint64_t)free_b + (uint64_t)w.pool.cap * 92u) / 4u / 92u;
             const uint64_t cap_rays = std::min<uint64_t>(std::max<uint64_t>(room, 64ull << 20), (1ull << 32) - 1);
             uint64_t b = cap_rays / need.per_batch;
             batch = (uint32_t)std::min<uint64_t>(8u << 20, std::max<uint64_t>(b / RTX_BLOCK * RTX_BLOCK, 256u << 10));
@@ -940,6 +940,10 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     const bool sort_all = std::getenv("RTX_SORT_ALL") != nullptr;
     const bool sort_steps = !noalloc && opt->shadow_samples > 0 && per_lane_shadows && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) &&
                             (!s->d.all_opaque || std::getenv("RTX_SORT_OPAQUE") != nullptr) && std::getenv("RTX_NO_SORT") == nullptr;
+    // The same for the closest-hit launch of those scenes (DPool.cell, rtxk_sort_rays): RTX_NO_RAY_SORT=1 for A/B.
+    const bool sort_rays_frame = !noalloc && (!s->d.all_opaque || std::getenv("RTX_SORT_OPAQUE") != nullptr) &&
+                                 std::getenv("RTX_NO_RAY_SORT") == nullptr && std::getenv("RTX_NO_SORT") == nullptr;
+    if (!sort_rays_frame) v.pool.cell = nullptr;   // (k_shade then writes no cells)
     uint32_t sort_min = 1u << 16, sort_gen = 1u;
     if (const char *e = std::getenv("RTX_SORT_MIN")) sort_min = (uint32_t)std::atoi(e);
     if (const char *e = std::getenv("RTX_SORT_GEN")) sort_gen = (uint32_t)std::atoi(e);
@@ -996,7 +1000,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         if (!sort_step) sq.cell = sq.order = nullptr;
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
                    overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace,
-                   sort_step ? &w.sortbuf : nullptr);
+                   (sort_step || sort_rays_frame) ? &w.sortbuf : nullptr, sort_rays_frame && (sort_all || (top_gen >= sort_gen && n >= sort_min)));
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));

@@ -161,11 +161,22 @@ struct DFrame {
 };
 
 // Ray pool: SoA, `cap` rays. f holds 9 component planes (origin, direction, throughput).
+// A ray of the pool: what the closest-hit walk and the shading need of it in ONE 64-byte line (four 16-byte loads of a lane; a launch
+// that takes its rays through an index touches one line per ray instead of one per plane), the throughput apart (k_shade alone reads it),
+// and the flags once more as a plane of their own for the passes that read nothing else of a ray (block_counts).
+struct DRayRec {
+    double o[3], d[3];
+    uint64_t key;       // RNG path key of the trace() call this ray stands for
+    uint32_t sample;    // primary sample the ray contributes to
+    uint32_t flags;
+};
+static_assert(sizeof(DRayRec) == 64, "one ray record per 64-byte line");
 struct DPool {
-    double *f;
-    uint64_t *key;      // RNG path key of the trace() call this ray stands for
-    uint32_t *sample;   // primary sample the ray contributes to
-    uint32_t *flags;
+    DRayRec *rec;       // [cap]
+    double *thr;        // [3][cap]
+    uint32_t *flags;    // [cap]
+    uint32_t *cell;     // [cap] sort key of a child ray: the octant of its direction (3 bits) over the cell of its origin (21-bit Morton code in
+                        // the scene's cube); written by k_shade, read by the sort that orders a later generation's closest-hit launch. NULL: unused
     uint32_t cap;
 };
 #define RAYF_REFLECT_SHIFT 0
@@ -242,17 +253,20 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 struct RtxTraceNames { const char *closest = ""; const char *shade = ""; };
 // what the sort of a step's shadow groups needs beside the queue's own arrays (shared by the two queues: the sorts run one after the
 // other on the main stream)
-struct RtxSortBuf { uint32_t *cell_sorted = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0; };
+struct RtxSortBuf { uint32_t *cell_sorted = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0; uint32_t *ray_order = nullptr; };
 size_t rtxk_sort_temp_bytes(uint32_t n);
 // orders the groups [0, n) of the queue by sq.cell (slots past *sq.count hold ~0 and come last) into sq.order; rtx_sort.hip
 void rtxk_sort_groups(rtx_stream_t stream, const DShadowQ &sq, const RtxSortBuf &sb, uint32_t n);
+// orders the rays [begin, begin + n) of the pool by pool.cell into sb.ray_order (indices relative to begin)
+void rtxk_sort_rays(rtx_stream_t stream, const DPool &pool, const RtxSortBuf &sb, uint32_t begin, uint32_t n);
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2 /* hipEvent_t or NULL: k_shade (it writes `sq`) waits for them, k_closest does not */,
                 void *record_after_closest /* hipEvent_t or NULL: recorded between the closest-hit launches and the shading launches (timing) */,
                 uint32_t *group_base /* [4 * ceil(count / RTX_BLOCK)]: rays that hit something per workgroup, their exclusive scan; children per workgroup, their scan */,
                 uint32_t child_begin /* the pool's tail before the step: where its children go */,
-                RtxTraceNames *names = nullptr, const RtxSortBuf *sortbuf = nullptr /* with sq.cell and sq.order: the step's groups are sorted */);
+                RtxTraceNames *names = nullptr, const RtxSortBuf *sortbuf = nullptr /* with sq.cell and sq.order: the step's groups are sorted */,
+                bool sort_rays = false /* with sortbuf and pool.cell: the closest-hit launch takes the step's rays by cell */);
 // returns the name of the kernel that does the launch's work ("" when nothing was launched)
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc,

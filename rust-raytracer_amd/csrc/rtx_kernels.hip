@@ -1713,13 +1713,27 @@ DEV uint32_t out_row(const DFrame &fr, uint32_t row) {
 
 DEV void pool_store(const DPool &pool, uint32_t slot, V3 o, V3 d, V3 thr, uint64_t key, uint32_t sample, uint32_t flags) {
     size_t cap = pool.cap;
-    double *f = pool.f + slot;
-    f[0 * cap] = o.x; f[1 * cap] = o.y; f[2 * cap] = o.z;
-    f[3 * cap] = d.x; f[4 * cap] = d.y; f[5 * cap] = d.z;
-    f[6 * cap] = thr.x; f[7 * cap] = thr.y; f[8 * cap] = thr.z;
-    pool.key[slot] = key;
-    pool.sample[slot] = sample;
+    double2 *r = reinterpret_cast<double2 *>(pool.rec + slot);   // (DRayRec: four 16-byte stores)
+    r[0] = make_double2(o.x, o.y);
+    r[1] = make_double2(o.z, d.x);
+    r[2] = make_double2(d.y, d.z);
+    r[3] = make_double2(__longlong_as_double((long long)key), __longlong_as_double((long long)(((uint64_t)flags << 32) | sample)));
+    double *t = pool.thr + slot;
+    t[0 * cap] = thr.x; t[1 * cap] = thr.y; t[2 * cap] = thr.z;
     pool.flags[slot] = flags;
+}
+struct PoolRay { V3 o, d; uint64_t key; uint32_t sample, flags; };
+DEV PoolRay pool_load(const DPool &pool, uint32_t slot) {
+    const double2 *r = reinterpret_cast<const double2 *>(pool.rec + slot);
+    const double2 a = r[0], b = r[1], c = r[2], e = r[3];
+    PoolRay p;
+    p.o = v3(a.x, a.y, b.x);
+    p.d = v3(b.y, c.x, c.y);
+    p.key = (uint64_t)__double_as_longlong(e.x);
+    const uint64_t sf = (uint64_t)__double_as_longlong(e.y);
+    p.sample = (uint32_t)sf;
+    p.flags = (uint32_t)(sf >> 32);
+    return p;
 }
 
 } // namespace
@@ -1735,6 +1749,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
     bool valid = decode_sample(fr, s, &px, &row, &sub);
     uint32_t slot = pool_base + gid;
     if (!valid) {
+        pool.rec[slot].flags = RAYF_DEAD;
         pool.flags[slot] = RAYF_DEAD;
         return;
     }
@@ -1765,16 +1780,22 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_WAVES : (MODE == MODE_CLOSEST_BVH_DEALT ? RTX_BVH_DEALT_WAVES : RTX_CLOSEST_WAVES)) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
-                                                                          DCounters *counters, double *hit_t, int32_t *hit_ref) {
+                                                                          DCounters *counters, double *hit_t, int32_t *hit_ref, const uint32_t *order) {
     constexpr bool BVH = MODE == MODE_CLOSEST_BVH || MODE == MODE_CLOSEST_BVH_DEALT;
     __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
     __shared__ __align__(8) uint32_t s_aux[MODE == MODE_CLOSEST_BVH_DEALT ? 4 * RTX_BLOCK : 2];   // traverse_bvh_dealt: best t (u64), ref and tie flag per lane
     if constexpr (!BVH) init_lds(s_stk);
+    // order != NULL: the launch takes the step's rays in the order of their cells (rtxk_sort_rays): lane gid walks ray order[gid]
+    // (one 64-byte record, wherever it lies) and writes that ray's hit record; everything after this kernel runs in ray order again
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
+    if (order && valid) gid = order[gid];
     uint32_t slot = begin + (valid ? gid : 0u);
-    uint32_t flags = valid ? pool.flags[slot] : RAYF_DEAD;
+    PoolRay pr;
+    pr.o = v3(0, 0, 0); pr.d = v3(0, 0, 1); pr.key = 0; pr.sample = 0; pr.flags = RAYF_DEAD;
+    if (valid) pr = pool_load(pool, slot);
+    uint32_t flags = pr.flags;
     valid = valid && !(flags & RAYF_DEAD);
     uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
     {
@@ -1790,36 +1811,25 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
     WORK(hit.w_nodes = hit.w_entries = hit.w_prims = 0;)
     if constexpr (MODE == MODE_CLOSEST) {
         // every lane of the wave takes part in the while-while walk (its flushes are wave-wide)
-        size_t cap = pool.cap;
-        const double *f = pool.f + slot;
-        Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
-                      : make_ray(v3(0, 0, 0), v3(0, 0, 1));
+        Ray r = valid ? make_ray(pr.o, pr.d) : make_ray(v3(0, 0, 0), v3(0, 0, 1));
         const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
         bool tie;
         traverse_ww<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit, nullptr, nullptr, &tie);
         if (degen || tie) hit.ref = REF_RETRY;
     } else if constexpr (MODE == MODE_CLOSEST_BVH) {
-        size_t cap = pool.cap;
-        const double *f = pool.f + slot;
-        Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
-                      : make_ray(v3(0, 0, 0), v3(0, 0, 1));
+        Ray r = valid ? make_ray(pr.o, pr.d) : make_ray(v3(0, 0, 0), v3(0, 0, 1));
         const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
         bool ovf;
         traverse_bvh<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, T_MIN, inf(), &hit, &ovf);
         if (degen || ovf) hit.ref = REF_RETRY;                          // (a full stack: the all-f64 walk answers the ray)
     } else if constexpr (MODE == MODE_CLOSEST_BVH_DEALT) {
-        size_t cap = pool.cap;
-        const double *f = pool.f + slot;
-        Ray r = valid ? make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]))
-                      : make_ray(v3(0, 0, 0), v3(0, 0, 1));
+        Ray r = valid ? make_ray(pr.o, pr.d) : make_ray(v3(0, 0, 0), v3(0, 0, 1));
         const bool degen = valid && degenerate_dir(r.dx, r.dy, r.dz);   // answered by k_closest_retry, launched next
         bool ovf;
         traverse_bvh_dealt<WW_CLOSEST>(sc, r, valid && !degen, s_stk, s_cand, s_aux, T_MIN, inf(), &hit, &ovf);
         if (degen || ovf) hit.ref = REF_RETRY;
     } else if (valid) {
-        size_t cap = pool.cap;
-        const double *f = pool.f + slot;
-        Ray r = make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]));
+        Ray r = make_ray(pr.o, pr.d);
         V3 unused;
         traverse<MODE>(sc, r, s_stk, T_MIN, inf(), &hit, &unused);
     }
@@ -1885,9 +1895,8 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool po
     if (__syncthreads_or(mine ? 1 : 0)) {   // hardly any block
         init_lds(s_stk);
         if (mine) {
-            const size_t cap = pool.cap;
-            const double *f = pool.f + begin + gid;
-            const Ray r = make_ray(v3(f[0 * cap], f[1 * cap], f[2 * cap]), v3(f[3 * cap], f[4 * cap], f[5 * cap]));
+            const PoolRay pr = pool_load(pool, begin + gid);
+            const Ray r = make_ray(pr.o, pr.d);
             Hit hit;
             V3 unused;
             traverse_exact<MODE_CLOSEST_REF>(sc, r, s_stk + threadIdx.x, T_MIN, inf(), &hit, &unused);
@@ -2014,6 +2023,13 @@ DEV uint32_t spread8(uint32_t x) {
     x = (x | (x << 2)) & 0x249249u;
     return x;
 }
+DEV uint32_t hit_cell(const DScene &sc, V3 p);
+// sort key of a child ray (DPool.cell): direction octant over the 21-bit cell of the origin
+DEV void pool_store_cell(const DPool &pool, const DScene &sc, uint32_t slot, V3 o, V3 d) {
+    if (!pool.cell) return;
+    const uint32_t oct = (d.x > 0.0 ? 1u : 0u) | (d.y > 0.0 ? 2u : 0u) | (d.z > 0.0 ? 4u : 0u);
+    pool.cell[slot] = (oct << 21) | (hit_cell(sc, o) >> 3);
+}
 DEV uint32_t hit_cell(const DScene &sc, V3 p) {
     const float s = 128.0f / (float)sc.radius;
     const float fx = fminf(fmaxf(((float)(p.x - sc.centre[0])) * s + 128.0f, 0.0f), 255.0f);
@@ -2033,7 +2049,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     uint32_t slot = begin + (valid ? gid : 0u);
     // The kernel waits for its fetches at 2 waves per SIMD, so what can be in flight together is asked for together: the ray's record
     // and hit with its flags (a dead ray's slot holds a ray all the same), then, below, the prim's class and its two records.
-    uint32_t flags = valid ? pool.flags[slot] : RAYF_DEAD;
+    uint32_t flags = RAYF_DEAD;
 
     size_t cap = pool.cap;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(0, 0, 0);
@@ -2043,12 +2059,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     hit.t = inf();
     hit.ref = REF_NONE;
     if (in_range) {
-        const double *f = pool.f + slot;
-        o = v3(f[0 * cap], f[1 * cap], f[2 * cap]);
-        d = v3(f[3 * cap], f[4 * cap], f[5 * cap]);
-        thr = v3(f[6 * cap], f[7 * cap], f[8 * cap]);
-        key = pool.key[slot];
-        sample = pool.sample[slot];
+        const PoolRay pr = pool_load(pool, slot);
+        const double *t3 = pool.thr + slot;
+        o = pr.o; d = pr.d; key = pr.key; sample = pr.sample; flags = pr.flags;
+        thr = v3(t3[0 * cap], t3[1 * cap], t3[2 * cap]);
         hit.t = hit_t[gid];
         hit.ref = hit_ref[gid];
     }
@@ -2212,6 +2226,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     if (n_reflect && !glossy) {   // mirror reflection (renderer.rs:164)
         pool_store(pool, cs, hp, rdir, scale(scale(thr, m.k_sg), reflect_fresnel), child_key(key, CODE_MIRROR), sample,
                    child_flags_reflect | ((uint32_t)RAY_REFLECT << RAYF_TYPE_SHIFT));
+        pool_store_cell(pool, sc, cs, hp, rdir);
     } else if (GENERAL && n_reflect) {       // glossy reflection: gloss_samples perturbed rays, averaged (renderer.rs:155-161)
         double inv_g = 1.0 / (double)fr.gloss_samples;
         for (uint32_t g = 0; g < n_reflect; ++g) {
@@ -2229,6 +2244,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
             V3 gdir = unit(corrected + rdir);
             pool_store(pool, cs + g, hp, gdir, scale(scale(scale(thr, inv_g), m.k_sg), reflect_fresnel), ck, sample,
                        child_flags_reflect | ((uint32_t)RAY_GLOSS << RAYF_TYPE_SHIFT));
+            pool_store_cell(pool, sc, cs + g, hp, gdir);
         }
     }
     if (spawn_transmit) {   // transmission (renderer.rs:170-186): TIR -> mirror direction with weight 1.0, `!inside` either way
@@ -2242,6 +2258,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
                       (inside ? 0u : RAYF_INSIDE) | ((uint32_t)RAY_REFRACT << RAYF_TYPE_SHIFT);
         pool_store(pool, cs + n_reflect, hp + scale(tdir, EPSILON), tdir, scale(scale(thr, m.k_tg), actual),
                    child_key(key, CODE_TRANSMIT), sample, cf);
+        pool_store_cell(pool, sc, cs + n_reflect, hp, tdir);
     }
 }
 
@@ -3349,7 +3366,7 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, uint32_t child_begin,
-                RtxTraceNames *names, const RtxSortBuf *sortbuf) {
+                RtxTraceNames *names, const RtxSortBuf *sortbuf, bool sort_rays) {
     if (count == 0) return;
     RtxTraceNames nm;
     static_assert(MODE_CLOSEST == 0 && MODE_CLOSEST_REF == 1 && MODE_CLOSEST_BVH == 5 && MODE_CLOSEST_BVH_DEALT == 8, "the kernel names below");
@@ -3361,9 +3378,14 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     const unsigned nb = grid_for(count);
     // group_base: four arrays of nb words: hits per workgroup, their exclusive scan, children per workgroup, their exclusive scan
     uint32_t *hit_count = want_groups ? group_base : nullptr, *hit_base = group_base + nb, *child_count = group_base + 2 * nb, *child_base = group_base + 3 * nb;
+    const uint32_t *order = nullptr;
+    if (sort_rays && sortbuf && pool.cell && sortbuf->ray_order) {
+        rtxk_sort_rays(stream, pool, *sortbuf, begin, count);
+        order = sortbuf->ray_order;
+    }
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
-                           count, counters, hit_t, hit_ref);
+                           count, counters, hit_t, hit_ref, order);
         hipLaunchKernelGGL(k_group_count, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_ref, fr.gloss_samples,
                            hit_count, child_count);
     } else
@@ -3372,13 +3394,13 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
         // out over the wave, see traverse_bvh_dealt)
         if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK) && !sc.all_opaque)
             hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH_DEALT>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
-                               count, counters, hit_t, hit_ref);
+                               count, counters, hit_t, hit_ref, order);
         else if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK))
             hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
-                               count, counters, hit_t, hit_ref);
+                               count, counters, hit_t, hit_ref, order);
         else
             hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
-                               counters, hit_t, hit_ref);
+                               counters, hit_t, hit_ref, order);
         hipLaunchKernelGGL(k_closest_retry, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
                            hit_ref, fr.gloss_samples, hit_count, child_count);
     }

@@ -240,8 +240,10 @@ def test_deferred_accumulation_equals_direct(rtx, orc, which, tries, monkeypatch
 @pytest.mark.parametrize("tries", [1, 3, 4, 16])
 def test_sorted_shadow_launches_equal_queue_order(rtx, orc, which, tries, monkeypatch):
     """The per-lane shadow launches of later generations take their groups in the order of the hit points' cells (DShadowQ.cell /
-    order, rtx_sort.hip) in scenes with transmissive materials; RTX_SORT_ALL + RTX_SORT_OPAQUE force the sort for every step of
-    every scene, RTX_NO_SORT switches it off.  The order of a launch's lanes changes nothing but the order of f64 additions:
+    order, rtx_sort.hip) in scenes with transmissive materials, and the closest-hit launches their rays by direction octant and
+    origin cell (DPool.cell, k_closest's `order`: lane i walks ray order[i] and writes that ray's hit record); RTX_SORT_ALL +
+    RTX_SORT_OPAQUE force both sorts for every step of every scene (the primaries too, whose cells nobody wrote: any permutation
+    must do), RTX_NO_SORT switches them off.  The order of a launch's lanes changes nothing but the order of f64 additions:
     same ids, same ray counts, images within one 8-bit step of each other and of the oracle.  Small batches (many steps, both
     queues in turn; slots past a step's count hold stale cells), overlapped and serial; 3 tries: groups that span waves."""
     if which == "kitchen":

@@ -1790,7 +1790,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
     // (one 64-byte record, wherever it lies) and writes that ray's hit record; everything after this kernel runs in ray order again
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool valid = gid < count;
-    if (order && valid) gid = order[gid];
+    if (order && valid) {
+        gid = order[gid];
+        valid = gid < count;   // (never false for a permutation; an index past the step is not followed)
+    }
     uint32_t slot = begin + (valid ? gid : 0u);
     PoolRay pr;
     pr.o = v3(0, 0, 0); pr.d = v3(0, 0, 1); pr.key = 0; pr.sample = 0; pr.flags = RAYF_DEAD;
@@ -2304,6 +2307,7 @@ DEV void shadow_kernel_body(const DScene &sc, const DFrame &fr, const DShadowQ &
         if ((uint64_t)blk * RTX_BLOCK >= (uint64_t)n_list * tries) return;   // (the whole workgroup)
         valid = group < n_list;
         group = valid ? group_list[1u + group] : 0u;
+        valid = valid && group < n_groups;   // (a list is the device's own work: an index past the queue is never followed)
     }
     const uint32_t feeler = group * tries + k;   // its index in the launch's queue (retry list entries)
     size_t qc = sq.cap;

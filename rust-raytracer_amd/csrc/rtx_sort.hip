@@ -19,6 +19,11 @@ static unsigned sort_begin_bit() {
 }
 
 __global__ void k_order_count(const uint32_t *count, uint32_t *order) { order[0] = *count; }
+// what a sort that could not be launched leaves behind: the order the launches would have had without it
+__global__ void k_order_identity(uint32_t *order, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = i;
+}
 
 size_t rtxk_sort_temp_bytes(uint32_t n) {
     size_t bytes = 0;
@@ -32,8 +37,11 @@ void rtxk_sort_groups(rtx_stream_t stream, const DShadowQ &sq, const RtxSortBuf 
     size_t bytes = sb.tmp_bytes;
     // (values: the group indices 0, 1, 2, .. from a counting iterator; the sort is stable, so the groups of one cell keep their ray order
     // and the stale slots past the queue's count, whose cell is ~0, stay behind every group of the step)
-    (void)rocprim::radix_sort_pairs(sb.tmp, bytes, sq.cell, sb.cell_sorted, rocprim::counting_iterator<uint32_t>(0u), sq.order + 1, n, sort_begin_bit(),
-                                    RTX_CELL_BITS, (hipStream_t)stream);
+    if (rocprim::radix_sort_pairs(sb.tmp, bytes, sq.cell, sb.cell_sorted, rocprim::counting_iterator<uint32_t>(0u), sq.order + 1, n, sort_begin_bit(),
+                                  RTX_CELL_BITS, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_order_identity, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sq.order + 1, n);
+    }
     hipLaunchKernelGGL(k_order_count, dim3(1), dim3(1), 0, (hipStream_t)stream, sq.count, sq.order);
 }
 
@@ -43,6 +51,9 @@ void rtxk_sort_groups(rtx_stream_t stream, const DShadowQ &sq, const RtxSortBuf 
 void rtxk_sort_rays(rtx_stream_t stream, const DPool &pool, const RtxSortBuf &sb, uint32_t begin, uint32_t n) {
     if (n == 0 || !pool.cell || !sb.ray_order || !sb.cell_sorted) return;
     size_t bytes = sb.tmp_bytes;
-    (void)rocprim::radix_sort_pairs(sb.tmp, bytes, pool.cell + begin, sb.cell_sorted, rocprim::counting_iterator<uint32_t>(0u), sb.ray_order, n, 0u,
-                                    RTX_CELL_BITS, (hipStream_t)stream);
+    if (rocprim::radix_sort_pairs(sb.tmp, bytes, pool.cell + begin, sb.cell_sorted, rocprim::counting_iterator<uint32_t>(0u), sb.ray_order, n, 0u,
+                                  RTX_CELL_BITS, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_order_identity, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sb.ray_order, n);
+    }
 }

@@ -400,6 +400,8 @@ struct Work {
     uint32_t sort_cap = 0;
     DCounters *d_counters = nullptr;
     DCounters *h_up = nullptr, *h_back = nullptr;   // pinned
+    uint32_t *h_step = nullptr, *d_step = nullptr;  // pinned, coherent: (pool tail, overflow, sequence number) of the step, stored by k_group_base, polled by the host
+    uint32_t step_seq = 0;
     unsigned long long (*d_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr;
     unsigned long long (*h_ray_slots)[RTX_RAY_SLOT_WORDS] = nullptr; // pinned
     double *hit_t = nullptr;
@@ -578,6 +580,7 @@ void free_work(Work &w) {
     if (w.h_ray_slots) hipHostFree(w.h_ray_slots);
     if (w.h_up) hipHostFree(w.h_up);
     if (w.h_back) hipHostFree(w.h_back);
+    if (w.h_step) hipHostFree(w.h_step);
     if (w.acc) hipFree(w.acc);
     if (w.out_rgba) hipFree(w.out_rgba);
     if (w.out_ids) hipFree(w.out_ids);
@@ -649,6 +652,9 @@ rtx_status ensure_work(rtx_scene *s, uint32_t pool_cap, uint32_t batch, size_t n
         if ((st = dev_alloc(&w.d_counters, 1))) return st;
         HIPCHECK(hipHostMalloc((void **)&w.h_up, sizeof(DCounters), hipHostMallocDefault));
         HIPCHECK(hipHostMalloc((void **)&w.h_back, sizeof(DCounters), hipHostMallocDefault));
+        HIPCHECK(hipHostMalloc((void **)&w.h_step, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(w.h_step, 0, 4 * sizeof(uint32_t));
+        HIPCHECK(hipHostGetDevicePointer((void **)&w.d_step, w.h_step, 0));
         HIPCHECK(hipMalloc((void **)&w.d_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long)));
         HIPCHECK(hipHostMalloc((void **)&w.h_ray_slots, RTX_RAY_SLOTS * RTX_RAY_SLOT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     }
@@ -966,6 +972,27 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         return e;
     };
     uint32_t back_tail = 0, back_overflow = 0;
+    // The host sizes the next step from this step's children.  k_group_base knows their number BEFORE k_shade runs and stores it (with the
+    // overflow flag and the step's sequence number) into pinned host memory; the host polls for the number instead of waiting for a copy
+    // and an event behind k_shade, and enqueues the next closest-hit launch while this step still shades: no idle chip between steps
+    // (measured: sphere 0.198 -> 0.183 ms, bunny 3.95 -> 3.87 ms, sibenik and sponza unchanged).  RTX_NO_POLL=1: the copy and the event (A/B).  Every 4096 looks the stream is asked whether it
+    // has finished or failed without the number having arrived; then the counters are fetched by a copy, as before.
+    const bool poll_step = !noalloc && w.d_step != nullptr && std::getenv("RTX_NO_POLL") == nullptr;
+    auto wait_step = [&](uint32_t seq, uint32_t *tail, uint32_t *ovf) -> rtx_status {
+        uint32_t looks = 0;
+        while (__atomic_load_n(&w.h_step[2], __ATOMIC_ACQUIRE) != seq) {
+            if ((++looks & 0xFFFu) != 0u) continue;
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return fail(RTX_ERR_HIP, std::string("wavefront step: ") + hipGetErrorString(q));
+            if (__atomic_load_n(&w.h_step[2], __ATOMIC_ACQUIRE) == seq) break;
+            HIPCHECK(hipMemcpy(w.h_back, v.d_counters, offsetof(DCounters, ray_slots), hipMemcpyDeviceToHost));
+            *tail = w.h_back->pool_tail; *ovf = w.h_back->overflow;
+            return RTX_OK;
+        }
+        *tail = w.h_step[0]; *ovf = w.h_step[1];
+        return RTX_OK;
+    };
     // one wavefront step; a non-zero status is returned through bail()
     auto one_step = [&]() -> rtx_status {
         if (n_segs == 0) {
@@ -994,13 +1021,20 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
             if ((st = next_event(&sp_c.a)) || (st = next_event(&sp_c.b)) || (st = next_event(&sp_c.mid))) return st;
             HIPCHECK(hipEventRecord(sp_c.a, stream));
         }
+        // (the step's outcome comes back through pinned memory as soon as k_group_base knows it: see wait_step)
+        uint32_t step_seq = 0;
+        if (poll_step) {
+            if (++w.step_seq == 0u) ++w.step_seq;
+            step_seq = w.step_seq;
+        }
         DShadowQ sq = (overlap && (step & 1u)) ? v.sq2 : v.sq;
         if (direct_acc) sq.res = nullptr;   // A/B: every shadow launch adds its results to the samples itself
         const bool sort_step = sort_steps && (sort_all || (top_gen >= sort_gen && n >= sort_min));
         if (!sort_step) sq.cell = sq.order = nullptr;
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
                    overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace,
-                   (sort_step || sort_rays_frame) ? &w.sortbuf : nullptr, sort_rays_frame && (sort_all || (top_gen >= sort_gen && n >= sort_min)));
+                   (sort_step || sort_rays_frame) ? &w.sortbuf : nullptr, sort_rays_frame && (sort_all || (top_gen >= sort_gen && n >= sort_min)),
+                   poll_step ? w.d_step : nullptr, step_seq);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));
@@ -1010,7 +1044,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         // spawned, overflow) to size the NEXT closest-hit launch
         hipEvent_t ev_back = nullptr;
         if (!noalloc) {
-            HIPCHECK(hipMemcpyAsync(w.h_back, v.d_counters, offsetof(DCounters, ray_slots), hipMemcpyDeviceToHost, stream));
+            if (!poll_step) HIPCHECK(hipMemcpyAsync(w.h_back, v.d_counters, offsetof(DCounters, ray_slots), hipMemcpyDeviceToHost, stream));
             if (overlap) {
                 if ((st = next_event(&ev_back))) return st;
                 HIPCHECK(hipEventRecord(ev_back, stream));
@@ -1060,8 +1094,14 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
                 if (!sq_free[step & 1u][a] && (st = next_event(&sq_free[step & 1u][a]))) return st;
                 HIPCHECK(hipEventRecord(sq_free[step & 1u][a], w.aux[a]));
             }
-            HIPCHECK(hipEventSynchronize(ev_back));   // the counters are back; the shadow launches go on
-            back_tail = w.h_back->pool_tail; back_overflow = w.h_back->overflow;
+            if (poll_step) {
+                if ((st = wait_step(step_seq, &back_tail, &back_overflow))) return st;
+            } else {
+                HIPCHECK(hipEventSynchronize(ev_back));   // the counters are back; the shadow launches go on
+                back_tail = w.h_back->pool_tail; back_overflow = w.h_back->overflow;
+            }
+        } else if (poll_step) {
+            if ((st = wait_step(step_seq, &back_tail, &back_overflow))) return st;
         } else {
             HIPCHECK(hipStreamSynchronize(stream));
             back_tail = w.h_back->pool_tail; back_overflow = w.h_back->overflow;

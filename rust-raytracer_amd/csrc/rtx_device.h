@@ -266,7 +266,9 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                 uint32_t *group_base /* [4 * ceil(count / RTX_BLOCK)]: rays that hit something per workgroup, their exclusive scan; children per workgroup, their scan */,
                 uint32_t child_begin /* the pool's tail before the step: where its children go */,
                 RtxTraceNames *names = nullptr, const RtxSortBuf *sortbuf = nullptr /* with sq.cell and sq.order: the step's groups are sorted */,
-                bool sort_rays = false /* with sortbuf and pool.cell: the closest-hit launch takes the step's rays by cell */);
+                bool sort_rays = false /* with sortbuf and pool.cell: the closest-hit launch takes the step's rays by cell */,
+                uint32_t *host_step = nullptr /* pinned host memory, 3 words: k_group_base stores the pool's tail after the step, the overflow flag and */,
+                uint32_t host_seq = 0 /* ... this number (last, with release semantics): the host polls for it */);
 // returns the name of the kernel that does the launch's work ("" when nothing was launched)
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc,

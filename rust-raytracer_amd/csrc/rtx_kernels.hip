@@ -1947,7 +1947,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_group_count(DScene sc, DPool pool
 // for this step, past the step's children, or raises the overflow flag if they do not fit: k_shade then writes none of those).
 __global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_count, const uint32_t *child_count, uint32_t n_blocks, uint32_t *block_base,
                                                           uint32_t *child_base, uint32_t *total_out, uint32_t child_begin, uint32_t pool_cap,
-                                                          DCounters *counters) {
+                                                          DCounters *counters, uint32_t *host_step, uint32_t host_seq) {
     __shared__ uint32_t s_pre[2][RTX_BLOCK / 64], s_wave[2][RTX_BLOCK / 64];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t seg0 = blockIdx.x * RTX_BLOCK, i = seg0 + threadIdx.x;
@@ -1995,8 +1995,17 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_group_base(const uint32_t *block_
     }
     if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) {
         if (block_count) *total_out = total[0];
-        if ((uint64_t)child_begin + total[1] > (uint64_t)pool_cap) counters->overflow = 1u;
+        const bool ovf = (uint64_t)child_begin + total[1] > (uint64_t)pool_cap;
+        if (ovf) counters->overflow = 1u;
         else counters->pool_tail = child_begin + total[1];
+        // What the host needs to size the NEXT step is known here, before k_shade has run: told to it at once, by a store into pinned host
+        // memory that it polls (tail, overflow, then the step's sequence number with release semantics at system scope), instead of a
+        // copy and an event after k_shade: the host enqueues the next closest-hit launch while this step is still shading.
+        if (host_step) {
+            host_step[0] = ovf ? child_begin : child_begin + total[1];
+            host_step[1] = ovf ? 1u : 0u;
+            __hip_atomic_store(host_step + 2, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -3370,7 +3379,7 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, uint32_t child_begin,
-                RtxTraceNames *names, const RtxSortBuf *sortbuf, bool sort_rays) {
+                RtxTraceNames *names, const RtxSortBuf *sortbuf, bool sort_rays, uint32_t *host_step, uint32_t host_seq) {
     if (count == 0) return;
     RtxTraceNames nm;
     static_assert(MODE_CLOSEST == 0 && MODE_CLOSEST_REF == 1 && MODE_CLOSEST_BVH == 5 && MODE_CLOSEST_BVH_DEALT == 8, "the kernel names below");
@@ -3413,7 +3422,7 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     if (wait_before_shade2) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade2, 0);
     // (after the waits: it writes the queue's group count) also moves the pool's tail past the step's children
     hipLaunchKernelGGL(k_group_base, dim3(grid_for(nb)), dim3(RTX_BLOCK), 0, (hipStream_t)stream, hit_count, child_count, nb, hit_base, child_base,
-                       sq.count, child_begin, pool.cap, counters);
+                       sq.count, child_begin, pool.cap, counters, host_step, host_seq);
     const bool sorted = want_groups && sortbuf && sq.cell && sq.order;
     if (!sorted) sq.cell = nullptr;
     if (sorted) (void)hipMemsetAsync(sq.cell, 0xFF, (size_t)count * sizeof(uint32_t), (hipStream_t)stream);   // (slots past the queue's count sort last)

@@ -65,10 +65,18 @@ def main():
             lo_, hi_ = o.min(0), o.max(0)
             octant = ((d[:, 0] > 0).astype(np.int64) | ((d[:, 1] > 0).astype(np.int64) << 1) | ((d[:, 2] > 0).astype(np.int64) << 2))
             m30 = morton30(o, lo_, hi_)
+            q4 = np.clip(((d + 1.0) * 2.0).astype(np.int64), 0, 3)      # 2 bits per direction component (sign + half)
+            dir6 = q4[:, 0] | (q4[:, 1] << 2) | (q4[:, 2] << 4)
+            q8 = np.clip(((d + 1.0) * 4.0).astype(np.int64), 0, 7)
+            dir9 = q8[:, 0] | (q8[:, 1] << 3) | (q8[:, 2] << 6)
             keys = {"random": rng.permutation(len(o)), "origin30": np.argsort(m30, kind="stable"),
                     "origin30_then_octant": np.argsort(m30 * 8 + octant, kind="stable"),
                     "octant_then_origin30": np.argsort((octant << 30) | m30, kind="stable"),
                     "octant_then_origin21": np.argsort((octant << 21) | (m30 >> 9), kind="stable"),
+                    "dir6_then_origin18": np.argsort((dir6 << 18) | (m30 >> 12), kind="stable"),
+                    "dir9_then_origin15": np.argsort((dir9 << 15) | (m30 >> 15), kind="stable"),
+                    "origin9_octant_origin12": np.argsort(((m30 >> 21) << 15) | (octant << 12) | ((m30 >> 9) & 0xFFF), kind="stable"),
+                    "origin6_octant_origin15": np.argsort(((m30 >> 24) << 18) | (octant << 15) | ((m30 >> 9) & 0x7FFF), kind="stable"),
                     "origin18": np.argsort(m30 >> 12, kind="stable"),
                     "origin18_then_octant": np.argsort((m30 >> 12) * 8 + octant, kind="stable")}
             for name, perm in keys.items():

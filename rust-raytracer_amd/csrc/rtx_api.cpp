@@ -945,7 +945,8 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
     }
     const bool sort_all = std::getenv("RTX_SORT_ALL") != nullptr;
     const bool sort_steps = !noalloc && opt->shadow_samples > 0 && per_lane_shadows && !(fr.flags & RTX_FLAG_INTERNAL_EXACT_SHADOWS) &&
-                            (!s->d.all_opaque || std::getenv("RTX_SORT_OPAQUE") != nullptr) && std::getenv("RTX_NO_SORT") == nullptr;
+                            (!s->d.all_opaque || std::getenv("RTX_SORT_OPAQUE") != nullptr) && std::getenv("RTX_NO_SORT") == nullptr &&
+                            std::getenv("RTX_NO_GROUP_SORT") == nullptr;
     // The same for the closest-hit launch of those scenes (DPool.cell, rtxk_sort_rays): RTX_NO_RAY_SORT=1 for A/B.
     const bool sort_rays_frame = !noalloc && (!s->d.all_opaque || std::getenv("RTX_SORT_OPAQUE") != nullptr) &&
                                  std::getenv("RTX_NO_RAY_SORT") == nullptr && std::getenv("RTX_NO_SORT") == nullptr;

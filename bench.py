@@ -292,7 +292,11 @@ def short_kernel_name(name):
     import re
     nm = name.replace("(anonymous namespace)::", "")
     m = re.match(r"(?:void\s+)?([\w:]+(?:<[^()]*?>)?)\s*\(", nm)
-    return m.group(1) if m else nm.split("(")[0].strip()
+    short = m.group(1) if m else nm.split("(")[0].strip()
+    # k_closest<MODE, PRIM> / k_shade<GENERAL, PRIM>: the instance for a step of primaries (which computes its rays) and the one for pool
+    # rays are one kernel to the accounting, as they are to rtx_last_kernel_names
+    m2 = re.match(r"(k_closest|k_shade)<([^,>]+),\s*(?:true|false)>$", short)
+    return "%s<%s>" % (m2.group(1), m2.group(2)) if m2 else short
 
 
 def child_cmd(args, extra):

@@ -994,12 +994,17 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         *tail = w.h_step[0]; *ovf = w.h_step[1];
         return RTX_OK;
     };
+    const bool use_generate = std::getenv("RTX_GENERATE") != nullptr;   // A/B: k_generate stores the primaries' records, as until the end of round 3
+    uint32_t seg0_s0 = 0;   // first sample of the batch of primaries in the pool
     // one wavefront step; a non-zero status is returned through bail()
     auto one_step = [&]() -> rtx_status {
         if (n_segs == 0) {
+            // a batch of primaries: pool slots [0, cnt) stand for the samples s_next .. s_next + cnt; nobody stores their records (the
+            // closest-hit and shading kernels compute a primary ray from its sample number: rtx_kernels.hip, primary_ray)
             uint32_t cnt = std::min<uint32_t>(batch, n_samples - s_next);
-            rtxk_generate(stream, fr, v.pool, 0, s_next, cnt);
+            if (use_generate) rtxk_generate(stream, fr, v.pool, 0, s_next, cnt);
             seg_push(Seg{0, cnt, 0});
+            seg0_s0 = s_next;
             s_next += cnt;
         }
         Seg &top = seg_top();
@@ -1035,7 +1040,7 @@ rtx_status render_once(rtx_scene *s, const rtx_camera *cam, const rtx_options *o
         rtxk_trace(stream, s->d, fr, v.pool, begin, n, sq, v.d_counters, v.acc, d_ids, v.hit_t, v.hit_ref,
                    overlap ? (void *)sq_free[step & 1u][0] : nullptr, overlap ? (void *)sq_free[step & 1u][1] : nullptr, (void *)sp_c.mid, v.group_base, top_end, &s->last_trace,
                    (sort_step || sort_rays_frame) ? &w.sortbuf : nullptr, sort_rays_frame && (sort_all || (top_gen >= sort_gen && n >= sort_min)),
-                   poll_step ? w.d_step : nullptr, step_seq);
+                   poll_step ? w.d_step : nullptr, step_seq, (top_gen == 0 && !use_generate) ? seg0_s0 : 0xFFFFFFFFu);
         ++launches_closest;
         if (timing) {
             HIPCHECK(hipEventRecord(sp_c.b, stream));

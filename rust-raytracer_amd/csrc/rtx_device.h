@@ -268,7 +268,8 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
                 RtxTraceNames *names = nullptr, const RtxSortBuf *sortbuf = nullptr /* with sq.cell and sq.order: the step's groups are sorted */,
                 bool sort_rays = false /* with sortbuf and pool.cell: the closest-hit launch takes the step's rays by cell */,
                 uint32_t *host_step = nullptr /* pinned host memory, 3 words: k_group_base stores the pool's tail after the step, the overflow flag and */,
-                uint32_t host_seq = 0 /* ... this number (last, with release semantics): the host polls for it */);
+                uint32_t host_seq = 0 /* ... this number (last, with release semantics): the host polls for it */,
+                uint32_t prim_s0 = 0xFFFFFFFFu /* a step of primaries whose records nobody stored: pool slot i stands for sample prim_s0 + i (the kernels compute the ray) */);
 // returns the name of the kernel that does the launch's work ("" when nothing was launched)
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,
                  uint32_t tries, DCounters *counters, double *acc,

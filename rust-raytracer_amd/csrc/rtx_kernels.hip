@@ -1740,19 +1740,17 @@ DEV PoolRay pool_load(const DPool &pool, uint32_t slot) {
 
 // ================================================================================ kernels
 
-// K1 primary_gen: render_tile's loops (renderer.rs:72-92) + Camera::get_ray (camera.rs:62-68)
-__global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count) {
-    uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (gid >= count) return;
-    uint32_t s = s0 + gid;
+// K1 primary_gen: render_tile's loops (renderer.rs:72-92) + Camera::get_ray (camera.rs:62-68).  The primary ray of sample s is a function of
+// the frame alone: the kernels that need it (closest hit, shading) compute it where they would read a pool record, so a step of primaries
+// writes and reads no ray records at all (k_generate, which stored them, is kept for RTX_GENERATE=1: A/B).
+DEV uint32_t primary_flags(const DFrame &fr) {
+    return (fr.reflect_depth << RAYF_REFLECT_SHIFT) | (fr.refract_depth << RAYF_REFRACT_SHIFT) | ((uint32_t)RAY_PRIMARY << RAYF_TYPE_SHIFT);
+}
+DEV PoolRay primary_ray(const DFrame &fr, uint32_t s) {
+    PoolRay pr;
+    pr.o = v3(0, 0, 0); pr.d = v3(0, 0, 1); pr.key = 0; pr.sample = s; pr.flags = RAYF_DEAD;
     uint32_t px, row, sub;
-    bool valid = decode_sample(fr, s, &px, &row, &sub);
-    uint32_t slot = pool_base + gid;
-    if (!valid) {
-        pool.rec[slot].flags = RAYF_DEAD;
-        pool.flags[slot] = RAYF_DEAD;
-        return;
-    }
+    if (!decode_sample(fr, s, &px, &row, &sub)) return pr;
     uint32_t abs_x = px, abs_y = fr.H - row - 1u;                                        // renderer.rs:73
     uint32_t x_subpixel = sub % fr.ps, y_subpixel = sub / fr.ps;
     uint64_t key = root_key(fr.seed, fr.frame, abs_y * fr.W + abs_x, sub);
@@ -1766,10 +1764,35 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
     double x = (double)abs_x + j_x, y = (double)abs_y + j_y;
     V3 eye = v3(fr.eye[0], fr.eye[1], fr.eye[2]), right = v3(fr.right[0], fr.right[1], fr.right[2]);
     V3 up = v3(fr.up[0], fr.up[1], fr.up[2]);
-    V3 dir = unit(eye + scale(right, x * fr.pixel_width - fr.half_width) + scale(up, y * fr.pixel_height - fr.half_height));
-    uint32_t flags = (fr.reflect_depth << RAYF_REFLECT_SHIFT) | (fr.refract_depth << RAYF_REFRACT_SHIFT) |
-                     ((uint32_t)RAY_PRIMARY << RAYF_TYPE_SHIFT);
-    pool_store(pool, slot, v3(fr.pos[0], fr.pos[1], fr.pos[2]), dir, v3(1.0, 1.0, 1.0), key, s, flags);
+    pr.d = unit(eye + scale(right, x * fr.pixel_width - fr.half_width) + scale(up, y * fr.pixel_height - fr.half_height));
+    pr.o = v3(fr.pos[0], fr.pos[1], fr.pos[2]);
+    pr.key = key;
+    pr.flags = primary_flags(fr);
+    return pr;
+}
+// a ray of the step: pool slot `slot`, or for a step of primaries (prim_s0 != RTX_NOT_PRIMARY) the ray of sample prim_s0 + slot
+#define RTX_NOT_PRIMARY 0xFFFFFFFFu
+DEV PoolRay step_ray(const DPool &pool, const DFrame &fr, uint32_t slot, uint32_t prim_s0) {
+    if (prim_s0 != RTX_NOT_PRIMARY) return primary_ray(fr, prim_s0 + slot);
+    return pool_load(pool, slot);
+}
+// (the kernels that do a frame's work have an instance of their own for steps of primaries: the others are the code they were)
+template <bool PRIM>
+DEV PoolRay step_ray_t(const DPool &pool, const DFrame &fr, uint32_t slot, uint32_t prim_s0) {
+    if constexpr (PRIM) return primary_ray(fr, prim_s0 + slot);
+    else return pool_load(pool, slot);
+}
+__global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, uint32_t pool_base, uint32_t s0, uint32_t count) {
+    uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t slot = pool_base + gid;
+    const PoolRay pr = primary_ray(fr, s0 + gid);
+    if (pr.flags & RAYF_DEAD) {
+        pool.rec[slot].flags = RAYF_DEAD;
+        pool.flags[slot] = RAYF_DEAD;
+        return;
+    }
+    pool_store(pool, slot, pr.o, pr.d, v3(1.0, 1.0, 1.0), pr.key, pr.sample, pr.flags);
 }
 
 // K2 trace_closest: Ray::get_nearest_hit (ray.rs:44-66) for pool rays [begin, begin+count):
@@ -1778,9 +1801,10 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_generate(DFrame fr, DPool pool, u
 #ifndef RTX_CLOSEST_WAVES
 #define RTX_CLOSEST_WAVES 6
 #endif
-template <int MODE>
+template <int MODE, bool PRIM>
 __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_WAVES : (MODE == MODE_CLOSEST_BVH_DEALT ? RTX_BVH_DEALT_WAVES : RTX_CLOSEST_WAVES)) k_closest(DScene sc, DPool pool, uint32_t begin, uint32_t count,
-                                                                          DCounters *counters, double *hit_t, int32_t *hit_ref, const uint32_t *order) {
+                                                                          DCounters *counters, double *hit_t, int32_t *hit_ref, const uint32_t *order,
+                                                                          DFrame fr, uint32_t prim_s0) {
     constexpr bool BVH = MODE == MODE_CLOSEST_BVH || MODE == MODE_CLOSEST_BVH_DEALT;
     __shared__ uint32_t s_stk[BVH ? RTX_BVH_STACK * RTX_BLOCK : RTX_LDS_WORDS];
     __shared__ uint32_t s_cand[MODE == MODE_CLOSEST ? RTX_CAND_WORDS : (BVH ? RTX_BVH_CAND * RTX_BLOCK : 1)];
@@ -1797,7 +1821,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, MODE == MODE_CLOSEST_BVH ? RTX_BVH_
     uint32_t slot = begin + (valid ? gid : 0u);
     PoolRay pr;
     pr.o = v3(0, 0, 0); pr.d = v3(0, 0, 1); pr.key = 0; pr.sample = 0; pr.flags = RAYF_DEAD;
-    if (valid) pr = pool_load(pool, slot);
+    if (valid) pr = step_ray_t<PRIM>(pool, fr, slot, prim_s0);
     uint32_t flags = pr.flags;
     valid = valid && !(flags & RAYF_DEAD);
     uint32_t type = (flags >> RAYF_TYPE_SHIFT) & 7u;
@@ -1867,14 +1891,14 @@ DEV uint32_t spawn_counts(uint32_t cls, uint32_t flags, uint32_t gloss_samples, 
 }
 // the two per-workgroup sums (every thread of the workgroup calls it): rays that hit something, children they will spawn
 DEV void block_counts(const DScene &sc, const DPool &pool, uint32_t begin, uint32_t count, uint32_t gloss_samples, int32_t ref,
-                      uint32_t *block_count, uint32_t *child_count, uint32_t *s_w /* 8 words */) {
+                      uint32_t *block_count, uint32_t *child_count, uint32_t *s_w /* 8 words */, uint32_t prim_flags /* 0: the rays' own */) {
     const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const bool hit = gid < count && ref != REF_NONE;   // (k_closest writes REF_NONE for dead rays)
     uint32_t nc = 0u;
     if (hit) {
         uint32_t n_reflect;
         bool transmit;
-        nc = spawn_counts(ref_class_of(sc, ref), pool.flags[begin + gid], gloss_samples, &n_reflect, &transmit);
+        nc = spawn_counts(ref_class_of(sc, ref), prim_flags ? prim_flags : pool.flags[begin + gid], gloss_samples, &n_reflect, &transmit);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nc += (uint32_t)__shfl_xor((int)nc, off);
@@ -1889,7 +1913,8 @@ DEV void block_counts(const DScene &sc, const DPool &pool, uint32_t begin, uint3
 
 // The all-f64 walk in the reference's visitation order for the rays k_closest<MODE_CLOSEST> has marked REF_RETRY (degenerate_dir).
 __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool pool, uint32_t begin, uint32_t count, double *hit_t,
-                                                             int32_t *hit_ref, uint32_t gloss_samples, uint32_t *block_count, uint32_t *child_count) {
+                                                             int32_t *hit_ref, uint32_t gloss_samples, uint32_t *block_count, uint32_t *child_count,
+                                                             DFrame fr, uint32_t prim_s0) {
     __shared__ uint32_t s_stk[RTX_LDS_WORDS];
     __shared__ uint32_t s_w[8];
     const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
@@ -1898,7 +1923,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool po
     if (__syncthreads_or(mine ? 1 : 0)) {   // hardly any block
         init_lds(s_stk);
         if (mine) {
-            const PoolRay pr = pool_load(pool, begin + gid);
+            const PoolRay pr = step_ray(pool, fr, begin + gid, prim_s0);
             const Ray r = make_ray(pr.o, pr.d);
             Hit hit;
             V3 unused;
@@ -1910,7 +1935,7 @@ __global__ void __launch_bounds__(RTX_BLOCK) k_closest_retry(DScene sc, DPool po
     }
     // this pass sees every ray's final hit: the workgroup's number of rays that hit something, for the compact shadow queue, and of
     // the children they spawn, for their slots in the pool (as k_group_count, which runs where this kernel does not)
-    block_counts(sc, pool, begin, count, gloss_samples, ref, block_count, child_count, s_w);
+    block_counts(sc, pool, begin, count, gloss_samples, ref, block_count, child_count, s_w, prim_s0 != RTX_NOT_PRIMARY ? primary_flags(fr) : 0u);
 }
 
 // A degenerate shadow feeler (degenerate_dir) is left out of the any-hit kernels' sums and appended to the launch's retry list:
@@ -1934,10 +1959,10 @@ DEV void retry_append(const DShadowQ &sq, uint32_t light, uint32_t feeler, uint3
 // (k_group_base); k_shade adds the ray's rank within its workgroup.  The children's slots in the pool: the same with the numbers of children.
 static_assert(RTX_BLOCK == 256, "the workgroup counts are summed over four waves");
 __global__ void __launch_bounds__(RTX_BLOCK) k_group_count(DScene sc, DPool pool, uint32_t begin, uint32_t count, const int32_t *hit_ref,
-                                                           uint32_t gloss_samples, uint32_t *block_count, uint32_t *child_count) {
+                                                           uint32_t gloss_samples, uint32_t *block_count, uint32_t *child_count, uint32_t prim_flags) {
     __shared__ uint32_t s_w[8];
     const uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
-    block_counts(sc, pool, begin, count, gloss_samples, gid < count ? hit_ref[gid] : REF_NONE, block_count, child_count, s_w);
+    block_counts(sc, pool, begin, count, gloss_samples, gid < count ? hit_ref[gid] : REF_NONE, block_count, child_count, s_w, prim_flags);
 }
 // One workgroup per 256 counts, every load coalesced: a workgroup first sums the counts before its segment, then scans its own.
 // (One workgroup whose threads each walked 32 consecutive counts touched a cache line per lane and load: 17 us on one CU.  Workgroups
@@ -2049,11 +2074,11 @@ DEV uint32_t hit_cell(const DScene &sc, V3 p) {
     const float fz = fminf(fmaxf(((float)(p.z - sc.centre[2])) * s + 128.0f, 0.0f), 255.0f);
     return spread8((uint32_t)fx) | (spread8((uint32_t)fy) << 1) | (spread8((uint32_t)fz) << 2);
 }
-template <bool GENERAL>
+template <bool GENERAL, bool PRIM>
 __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHADE_WAVES_LEAN) k_shade(DScene sc, DFrame fr, DPool pool, uint32_t begin, uint32_t count,
                                                      const double *hit_t, const int32_t *hit_ref, DShadowQ sq, DCounters *counters,
                                                      double *acc, int32_t *prim_id_out, const uint32_t *group_base,
-                                                     const uint32_t *child_base, uint32_t child_begin) {
+                                                     const uint32_t *child_base, uint32_t child_begin, uint32_t prim_s0) {
     __shared__ uint32_t s_tmp[8];
     uint32_t gid = blockIdx.x * RTX_BLOCK + threadIdx.x;
     bool in_range = gid < count;
@@ -2071,10 +2096,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, GENERAL ? RTX_SHADE_WAVES : RTX_SHA
     hit.t = inf();
     hit.ref = REF_NONE;
     if (in_range) {
-        const PoolRay pr = pool_load(pool, slot);
+        const PoolRay pr = step_ray_t<PRIM>(pool, fr, slot, prim_s0);
         const double *t3 = pool.thr + slot;
         o = pr.o; d = pr.d; key = pr.key; sample = pr.sample; flags = pr.flags;
-        thr = v3(t3[0 * cap], t3[1 * cap], t3[2 * cap]);
+        if constexpr (PRIM) thr = v3(1.0, 1.0, 1.0);
+        else thr = v3(t3[0 * cap], t3[1 * cap], t3[2 * cap]);
         hit.t = hit_t[gid];
         hit.ref = hit_ref[gid];
     }
@@ -3379,7 +3405,7 @@ void rtxk_generate(rtx_stream_t stream, const DFrame &fr, DPool pool, uint32_t p
 void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool pool, uint32_t begin, uint32_t count,
                 DShadowQ sq, DCounters *counters, double *acc, int32_t *prim_id_out, double *hit_t, int32_t *hit_ref,
                 void *wait_before_shade, void *wait_before_shade2, void *record_after_closest, uint32_t *group_base, uint32_t child_begin,
-                RtxTraceNames *names, const RtxSortBuf *sortbuf, bool sort_rays, uint32_t *host_step, uint32_t host_seq) {
+                RtxTraceNames *names, const RtxSortBuf *sortbuf, bool sort_rays, uint32_t *host_step, uint32_t host_seq, uint32_t prim_s0) {
     if (count == 0) return;
     RtxTraceNames nm;
     static_assert(MODE_CLOSEST == 0 && MODE_CLOSEST_REF == 1 && MODE_CLOSEST_BVH == 5 && MODE_CLOSEST_BVH_DEALT == 8, "the kernel names below");
@@ -3391,31 +3417,40 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     const unsigned nb = grid_for(count);
     // group_base: four arrays of nb words: hits per workgroup, their exclusive scan, children per workgroup, their exclusive scan
     uint32_t *hit_count = want_groups ? group_base : nullptr, *hit_base = group_base + nb, *child_count = group_base + 2 * nb, *child_base = group_base + 3 * nb;
+    const bool prim = prim_s0 != RTX_NOT_PRIMARY;
     const uint32_t *order = nullptr;
     if (sort_rays && sortbuf && pool.cell && sortbuf->ray_order) {
         rtxk_sort_rays(stream, pool, *sortbuf, begin, count);
         order = sortbuf->ray_order;
     }
     if (fr.flags & RTX_FLAG_REFERENCE_ORDER) {
-        hipLaunchKernelGGL(k_closest<MODE_CLOSEST_REF>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
-                           count, counters, hit_t, hit_ref, order);
+        { if (prim) hipLaunchKernelGGL((k_closest<MODE_CLOSEST_REF, true>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                           count, counters, hit_t, hit_ref, order, fr, prim_s0);
+        else hipLaunchKernelGGL((k_closest<MODE_CLOSEST_REF, false>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                           count, counters, hit_t, hit_ref, order, fr, prim_s0); }
         hipLaunchKernelGGL(k_group_count, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_ref, fr.gloss_samples,
-                           hit_count, child_count);
+                           hit_count, child_count, prim_s0 != 0xFFFFFFFFu ? ((fr.reflect_depth << RAYF_REFLECT_SHIFT) | (fr.refract_depth << RAYF_REFRACT_SHIFT) | ((uint32_t)RAY_PRIMARY << RAYF_TYPE_SHIFT)) : 0u);
     } else
     {
         // (scenes with transmissive materials: rays run along the inside of thin shells and meet ten candidates each: the exact tests dealt
         // out over the wave, see traverse_bvh_dealt)
         if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK) && !sc.all_opaque)
-            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH_DEALT>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
-                               count, counters, hit_t, hit_ref, order);
+            { if (prim) hipLaunchKernelGGL((k_closest<MODE_CLOSEST_BVH_DEALT, true>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                               count, counters, hit_t, hit_ref, order, fr, prim_s0);
+        else hipLaunchKernelGGL((k_closest<MODE_CLOSEST_BVH_DEALT, false>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                               count, counters, hit_t, hit_ref, order, fr, prim_s0); }
         else if (sc.bvh4 && !(fr.flags & RTX_FLAG_OCTREE_WALK))
-            hipLaunchKernelGGL(k_closest<MODE_CLOSEST_BVH>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
-                               count, counters, hit_t, hit_ref, order);
+            { if (prim) hipLaunchKernelGGL((k_closest<MODE_CLOSEST_BVH, true>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                               count, counters, hit_t, hit_ref, order, fr, prim_s0);
+        else hipLaunchKernelGGL((k_closest<MODE_CLOSEST_BVH, false>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin,
+                               count, counters, hit_t, hit_ref, order, fr, prim_s0); }
         else
-            hipLaunchKernelGGL(k_closest<MODE_CLOSEST>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
-                               counters, hit_t, hit_ref, order);
+            { if (prim) hipLaunchKernelGGL((k_closest<MODE_CLOSEST, true>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
+                               counters, hit_t, hit_ref, order, fr, prim_s0);
+        else hipLaunchKernelGGL((k_closest<MODE_CLOSEST, false>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count,
+                               counters, hit_t, hit_ref, order, fr, prim_s0); }
         hipLaunchKernelGGL(k_closest_retry, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, pool, begin, count, hit_t,
-                           hit_ref, fr.gloss_samples, hit_count, child_count);
+                           hit_ref, fr.gloss_samples, hit_count, child_count, fr, prim_s0);
     }
     if (record_after_closest) (void)hipEventRecord((hipEvent_t)record_after_closest, (hipStream_t)stream);
     if (wait_before_shade) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_shade, 0);
@@ -3427,11 +3462,15 @@ void rtxk_trace(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DPool p
     if (!sorted) sq.cell = nullptr;
     if (sorted) (void)hipMemsetAsync(sq.cell, 0xFF, (size_t)count * sizeof(uint32_t), (hipStream_t)stream);   // (slots past the queue's count sort last)
     if (sc.shade_features || !(fr.flags & RTX_FLAG_INTERNAL_SMALL_SHADE))
-        hipLaunchKernelGGL(k_shade<true>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
-                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin);
+        { if (prim) hipLaunchKernelGGL((k_shade<true, true>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin, prim_s0);
+        else hipLaunchKernelGGL((k_shade<true, false>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin, prim_s0); }
     else
-        hipLaunchKernelGGL(k_shade<false>, dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
-                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin);
+        { if (prim) hipLaunchKernelGGL((k_shade<false, true>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin, prim_s0);
+        else hipLaunchKernelGGL((k_shade<false, false>), dim3(nb), dim3(RTX_BLOCK), 0, (hipStream_t)stream, sc, fr, pool, begin, count, hit_t,
+                           hit_ref, sq, counters, acc, prim_id_out, hit_base, child_base, child_begin, prim_s0); }
     if (sorted) rtxk_sort_groups(stream, sq, *sortbuf, count);
 }
 const char *rtxk_shadow(rtx_stream_t stream, const DScene &sc, const DFrame &fr, DShadowQ sq, uint32_t light, uint32_t n_groups,

@@ -272,3 +272,36 @@ def test_sorted_shadow_launches_equal_queue_order(rtx, orc, which, tries, monkey
         assert (np.abs(x[..., :3].astype(int) - o[..., :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
     assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3
     assert (np.abs(a2.astype(int) - b.astype(int)) <= 1).all() and (np.abs(d.astype(int) - b.astype(int)) <= 1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mesh_transmissive", "kitchen"])
+def test_computed_primaries_equal_stored_primaries(rtx, orc, which, monkeypatch):
+    """A step of primaries stores no ray records: the closest-hit and shading kernels compute the ray of sample s0 + slot where they
+    would read the pool (primary_ray; k_closest<MODE, true>, k_shade<GENERAL, true>).  RTX_GENERATE=1 keeps k_generate and the stored
+    records.  Same frames either way and against the oracle: several batches of primaries per frame (batch_rays below the sample count:
+    s0 > 0), jittered sub-samples, two shards of interleaved tile blocks (samples of foreign blocks are dead), the octree walks too."""
+    if which == "kitchen":
+        flat, cam_fn = scenes.kitchen_sink_scene(rtx)
+    else:
+        flat, cam_fn = scenes.mesh_scene(rtx, n_u=48, n_v=32, transmissive=True)
+    cam = cam_fn(168, 96)
+    sc = rtx.Scene(flat)
+    kw = dict(reflect_depth=3, refract_depth=3, shadow_samples=4, pixel_samples=2, rng_mode=1, seed=3, batch_rays=8192)
+    o, io, so = orc.Scene(flat).render(cam, rtx.options(**kw), threads=16)
+    for flags in (0, rtx.abi.FLAG_OCTREE_WALK, rtx.abi.FLAG_REFERENCE_ORDER):
+        a, ia, sa = sc.render(cam, rtx.options(flags=flags, **kw))
+        monkeypatch.setenv("RTX_GENERATE", "1")
+        b, ib, sb = sc.render(cam, rtx.options(flags=flags, **kw))
+        monkeypatch.delenv("RTX_GENERATE")
+        assert np.array_equal(ia, io) and np.array_equal(ib, io) and sa.rays_total == so.rays_total == sb.rays_total
+        assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a != b).mean() < 1e-3
+        assert (np.abs(a[..., :3].astype(int) - o[..., :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
+    # two shards: each renders its own 8-row blocks of the frame
+    full = np.zeros_like(o)
+    for k in range(2):
+        part, _, _ = sc.render(cam, rtx.options(shard_index=k, shard_count=2, **kw))
+        for blk in range(k, 96 // 8, 2):
+            full[blk * 8:blk * 8 + 8] = part[blk * 8:blk * 8 + 8]
+    sc.close()
+    assert (np.abs(full[..., :3].astype(int) - o[..., :3].astype(int)).max(axis=-1) <= 1).mean() >= 0.999
